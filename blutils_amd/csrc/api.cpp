@@ -1,0 +1,92 @@
+// C-ABI entry point of the hot path (include/blu_consensus.h): validates the
+// hit table, stages host buffers when asked to, launches the HIP kernel.
+// There is no CPU implementation behind this call: without a HIP device it
+// fails with BLU_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "blu_internal.h"
+
+using namespace blu;
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            set_error("%s failed: %s", #expr, hipGetErrorString(_e));              \
+            rc = BLU_ERR_HIP;                                                      \
+            goto done;                                                             \
+        }                                                                          \
+    } while (0)
+
+extern "C" {
+
+int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_run_params* params,
+                      blu_result* out) {
+    if (!tax || !hits || !params) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    if (tax->device < 0) { set_error("host-only taxonomy handle: blu_consensus_run needs a HIP device (no CPU fallback)"); return BLU_ERR_NO_DEVICE; }
+    if (params->strategy != BLU_CAUTIOUS && params->strategy != BLU_RELAXED) { set_error("unknown strategy %d", params->strategy); return BLU_ERR_INVALID_ARG; }
+    if (hits->n_hits >= 0xFFFFFFFFull) { set_error("n_hits must be < 2^32 - 1 per call"); return BLU_ERR_INVALID_ARG; }
+    if (hits->n_queries == 0) return BLU_OK;
+    if (!out || !hits->seg_off) { set_error("null output or seg_off"); return BLU_ERR_INVALID_ARG; }
+    if (hits->n_hits && (!hits->bitscore || !hits->tax_row || !hits->pident || !hits->align_len || !hits->acc_rank)) {
+        set_error("null hit column"); return BLU_ERR_INVALID_ARG;
+    }
+    if (hipSetDevice(tax->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", tax->device); return BLU_ERR_NO_DEVICE; }
+
+    TaxDev td{tax->d_lin, tax->d_cut, tax->d_codes, tax->n_tax, tax->stride, tax->sc};
+    if (hits->on_device) {
+        HitsDev hd{hits->bitscore, hits->tax_row, hits->pident, hits->align_len, hits->acc_rank, hits->seg_off,
+                   hits->n_hits, hits->n_queries};
+        return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus);
+    }
+
+    // host pointers: stage over PCIe, run, copy the records back (synchronous)
+    int rc = BLU_OK;
+    hipStream_t s = (hipStream_t)params->stream;
+    const size_t nh = hits->n_hits, nq = hits->n_queries;
+    void *d_bs = nullptr, *d_tax = nullptr, *d_pid = nullptr, *d_aln = nullptr, *d_acc = nullptr, *d_seg = nullptr, *d_out = nullptr;
+    {
+        const size_t pad = 64;  // keeps zero-length columns allocatable
+        HIP_TRY(hipMalloc(&d_bs, nh * 4 + pad));
+        HIP_TRY(hipMalloc(&d_tax, nh * 4 + pad));
+        HIP_TRY(hipMalloc(&d_pid, nh * 8 + pad));
+        HIP_TRY(hipMalloc(&d_aln, nh * 4 + pad));
+        HIP_TRY(hipMalloc(&d_acc, nh * 4 + pad));
+        HIP_TRY(hipMalloc(&d_seg, (nq + 1) * 8));
+        HIP_TRY(hipMalloc(&d_out, nq * sizeof(blu_result)));
+        if (nh) {
+            HIP_TRY(hipMemcpyAsync(d_bs, hits->bitscore, nh * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_tax, hits->tax_row, nh * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_pid, hits->pident, nh * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_aln, hits->align_len, nh * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_acc, hits->acc_rank, nh * 4, hipMemcpyHostToDevice, s));
+        }
+        HIP_TRY(hipMemcpyAsync(d_seg, hits->seg_off, (nq + 1) * 8, hipMemcpyHostToDevice, s));
+        HitsDev hd{(const int32_t*)d_bs, (const uint32_t*)d_tax, (const double*)d_pid, (const int32_t*)d_aln,
+                   (const uint32_t*)d_acc, (const uint64_t*)d_seg, hits->n_hits, hits->n_queries};
+        rc = launch_consensus(td, hd, params->strategy, (blu_result*)d_out, s, tax->device, tax->num_cus);
+        if (rc != BLU_OK) goto done;
+        HIP_TRY(hipMemcpyAsync(out, d_out, nq * sizeof(blu_result), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+done:
+    if (d_bs) (void)hipFree(d_bs);
+    if (d_tax) (void)hipFree(d_tax);
+    if (d_pid) (void)hipFree(d_pid);
+    if (d_aln) (void)hipFree(d_aln);
+    if (d_acc) (void)hipFree(d_acc);
+    if (d_seg) (void)hipFree(d_seg);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+int blu_consensus_last_launch(char* kernel_name, size_t len, uint32_t* grid, uint32_t* block) {
+    if (kernel_name && len) snprintf(kernel_name, len, "%s", consensus_kernel_name());
+    consensus_last_geometry(grid, block);
+    return BLU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// Internal declarations shared by the host side and the HIP kernels of
+// libblu_consensus.so.  Not part of the ABI (include/blu_consensus.h is).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "blu_consensus.h"
+
+namespace blu {
+
+// canonical rank codes: 0..8 = LinnaeanRank enum kinds (linnaean_ranks.rs:16-29),
+// >= 9 = Other(slug), interned in order of first appearance
+enum RankKind : uint16_t { K_UNDEFINED = 0, K_DOMAIN, K_KINGDOM, K_PHYLUM, K_CLASS, K_ORDER, K_FAMILY, K_GENUS,
+                           K_SPECIES, K_FIRST_OTHER };
+
+struct RankInfo {
+    std::string display;  // impl Display (linnaean_ranks.rs:74-89)
+    std::string serde;    // serde camelCase name / raw Other string
+};
+
+// Device view of the taxonomy (passed to kernels by value).
+struct TaxDev {
+    const uint32_t* lin;    // [n_tax][stride] word0 = len | shape << 8 (len 0 = bad lineage), words 1.. = node ids
+    const double* cut;      // [n_shapes][sc] per-level identity cutoff
+    const uint32_t* codes;  // [n_shapes][sc] rank_code | mar_code << 16
+    uint64_t n_tax;
+    uint32_t stride;        // words per lineage row, multiple of 16 (64-byte rows)
+    uint32_t sc;            // entries per shape row
+};
+
+struct HitsDev {
+    const int32_t* bitscore;
+    const uint32_t* tax_row;
+    const double* pident;
+    const int32_t* align_len;
+    const uint32_t* acc_rank;
+    const uint64_t* seg_off;
+    uint64_t n_hits;
+    uint64_t n_queries;
+};
+
+// launch wrapper implemented in consensus_kernel.hip
+int launch_consensus(const TaxDev& tax, const HitsDev& hits, int strategy, blu_result* out, void* stream,
+                     int device, int num_cus);
+const char* consensus_kernel_name();
+void consensus_last_geometry(uint32_t* grid, uint32_t* block);
+
+void set_error(const char* fmt, ...);
+
+}  // namespace blu
+
+struct blu_taxonomy {
+    int device = -1;
+    int num_cus = 0;
+    uint64_t n_tax = 0;
+    uint32_t stride = 16;
+    uint32_t sc = 16;
+    uint32_t max_depth = 0;
+    blu_cutoff_config cfg{};
+    std::vector<blu::RankInfo> ranks;        // by canonical code
+    std::vector<uint32_t> h_lin;             // host copy of the lineage rows
+    std::vector<double> h_cut;               // [n_shapes * sc]
+    std::vector<uint32_t> h_codes;           // [n_shapes * sc]
+    std::vector<uint8_t> h_isdef;            // [n_shapes * sc]
+    uint32_t n_shapes = 0;
+    std::unordered_map<int64_t, uint32_t> taxid_row;
+    uint32_t* d_lin = nullptr;
+    double* d_cut = nullptr;
+    uint32_t* d_codes = nullptr;
+    uint64_t device_bytes = 0;
+};

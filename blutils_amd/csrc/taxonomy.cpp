@@ -1,0 +1,342 @@
+// Host side of the taxonomy handle: canonical rank codes, rank-sequence
+// "shapes", per-shape cutoff tables, fixed-stride lineage rows, upload.
+//
+// Reference semantics restated here (product code — independent of oracle/):
+//   LinnaeanRank::from_str / Display        core/src/domain/dtos/linnaean_ranks.rs:52-89
+//   Taxon::get_taxon_cutoff + tables        core/src/domain/dtos/taxon.rs:104-185
+//   InterpolatedIdentity::interpolate_identities   linnaean_ranks.rs:220-383
+//   round(value, 3)                         core/src/domain/utils/mod.rs:1-4
+// The cutoffs are a pure function of (Taxon, CustomTaxon, rank sequence), so
+// they are computed once per distinct rank sequence instead of once per query.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+#include "blu_internal.h"
+
+namespace blu {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+// slugify 0.1 (third-party crate; ASCII behaviour): lowercase, keep [a-z0-9],
+// collapse every other run into one '-', trim '-' at both ends.
+static std::string slugify_ascii(const std::string& s) {
+    std::string out;
+    bool pending = false;
+    for (unsigned char c : s) {
+        if (c >= 'A' && c <= 'Z') c = (unsigned char)(c + 32);
+        bool keep = (c >= 'a' && c <= 'z') || (c >= '0' && c <= '9');
+        if (keep) {
+            if (pending && !out.empty()) out.push_back('-');
+            pending = false;
+            out.push_back((char)c);
+        } else {
+            pending = true;
+        }
+    }
+    return out;
+}
+
+// linnaean_ranks.rs:52-72: lowercase + trim, letters and full names map to the
+// enum, anything else to Other(slugify(x)).  Returns the enum kind (0..8) or
+// K_FIRST_OTHER with `other` set.
+static uint16_t parse_rank(const char* name, std::string* other) {
+    std::string low;
+    for (const unsigned char* p = (const unsigned char*)name; *p; ++p)
+        low.push_back((*p >= 'A' && *p <= 'Z') ? (char)(*p + 32) : (char)*p);
+    size_t a = 0, b = low.size();
+    while (a < b && isspace((unsigned char)low[a])) ++a;
+    while (b > a && isspace((unsigned char)low[b - 1])) --b;
+    low = low.substr(a, b - a);
+    static const struct { const char* letter; const char* full; uint16_t kind; } tab[] = {
+        {"u", "undefined", K_UNDEFINED}, {"d", "domain", K_DOMAIN}, {"k", "kingdom", K_KINGDOM},
+        {"p", "phylum", K_PHYLUM},       {"c", "class", K_CLASS},   {"o", "order", K_ORDER},
+        {"f", "family", K_FAMILY},       {"g", "genus", K_GENUS},   {"s", "species", K_SPECIES}};
+    for (auto& e : tab)
+        if (low == e.letter || low == e.full) return e.kind;
+    *other = slugify_ascii(low);
+    return K_FIRST_OTHER;
+}
+
+struct Backbone {
+    bool has[9] = {false};   // enum kind present as DefaultRank in the backbone
+    double cut[9] = {0};
+    double first = 0.0;      // backbone[0]'s identity (linnaean_ranks.rs:343-346)
+};
+
+// taxon.rs:104-185
+static int make_backbone(const blu_cutoff_config& cfg, Backbone* bb) {
+    auto set = [&](uint16_t k, double v) { bb->has[k] = true; bb->cut[k] = v; };
+    switch (cfg.taxon) {
+        case BLU_TAXON_FUNGI:
+        case BLU_TAXON_EUKARYOTES:  // taxon.rs:144-154, 174-184
+            set(K_SPECIES, 97.0); set(K_GENUS, 95.0); set(K_FAMILY, 90.0); set(K_ORDER, 85.0);
+            set(K_CLASS, 80.0); set(K_PHYLUM, 75.0); set(K_DOMAIN, 60.0);
+            bb->first = 97.0;
+            return BLU_OK;
+        case BLU_TAXON_BACTERIA:    // taxon.rs:159-169
+            set(K_SPECIES, 99.0); set(K_GENUS, 97.0); set(K_FAMILY, 92.0); set(K_ORDER, 85.0);
+            set(K_CLASS, 80.0); set(K_PHYLUM, 75.0); set(K_DOMAIN, 60.0);
+            bb->first = 99.0;
+            return BLU_OK;
+        case BLU_TAXON_CUSTOM: {    // taxon.rs:113-139
+            if (!cfg.has_custom) {
+                set_error("Custom taxon values are required (taxon.rs:117)");
+                return BLU_ERR_CUSTOM_MISSING;
+            }
+            static const uint16_t order[8] = {K_DOMAIN, K_KINGDOM, K_PHYLUM, K_CLASS, K_ORDER, K_FAMILY, K_GENUS, K_SPECIES};
+            for (int i = 0; i < 8; ++i) {
+                bool mandatory = (i == 0 || i == 7);
+                int16_t v = (mandatory || cfg.custom_has[i]) ? cfg.custom[i] : (int16_t)0;
+                set(order[i], (double)v);
+            }
+            bb->first = bb->cut[K_DOMAIN];
+            return BLU_OK;
+        }
+    }
+    set_error("unknown taxon %d", cfg.taxon);
+    return BLU_ERR_INVALID_ARG;
+}
+
+// linnaean_ranks.rs:220-383 in index form.  Two mapped entries compare equal
+// (the `position(|level| level == x)` searches) exactly when their canonical
+// rank codes are equal, so "first equal element" = first level with that code.
+static void interpolate_shape(const Backbone& bb, const uint16_t* code, int n, double* cut, uint8_t* isdef) {
+    bool all_default = true;
+    for (int i = 0; i < n; ++i) {
+        bool d = code[i] < K_FIRST_OTHER && bb.has[code[i]];
+        isdef[i] = d;
+        cut[i] = d ? bb.cut[code[i]] : 0.0;
+        all_default &= d;
+    }
+    if (all_default) return;  // :265-270
+    std::vector<double> base(cut, cut + n);
+    auto first_with_code = [&](uint16_t c) { for (int j = 0; j < n; ++j) if (code[j] == c) return j; return 0; };
+    for (int i = 0; i < n; ++i) {
+        if (isdef[i]) continue;
+        int prev = 0;                                     // :292-300
+        for (int j = i - 1; j >= 0; --j) if (isdef[j]) { prev = j; break; }
+        int prev_idx = first_with_code(code[prev]);       // :302-305
+        int next = n - 1;                                 // :307-317
+        for (int j = i; j < n; ++j) if (isdef[j]) { next = j; break; }
+        int next_idx = first_with_code(code[next]);       // :319-322
+        int wlen = std::min(next_idx + 1, n - prev_idx);  // :324-329 skip_while(!= previous).take(next_index + 1)
+        int wlast = prev_idx + wlen - 1;
+        double first = isdef[prev_idx] ? base[prev_idx] : bb.first;   // :341-347
+        double last = isdef[wlast] ? base[wlast] : 100.0;             // :349-353
+        double weight = last - first;                                 // :355
+        double size = (double)(wlen - 1);                             // :356
+        double step = weight / size;
+        double scaled = (double)(i - prev_idx) * step;                // :339, :360
+        double v = first + scaled;
+        cut[i] = std::round(v * 1000.0) / 1000.0;                     // utils/mod.rs:1-4
+    }
+}
+
+}  // namespace blu
+
+using namespace blu;
+
+extern "C" {
+
+uint32_t blu_abi_version(void) { return BLU_ABI_VERSION; }
+
+size_t blu_last_error(char* buf, size_t len) {
+    const std::string& e = blu::g_last_error;
+    if (buf && len) {
+        size_t n = std::min(len - 1, e.size());
+        memcpy(buf, e.data(), n);
+        buf[n] = 0;
+    }
+    return e.size();
+}
+
+int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* cfg, int device,
+                        blu_taxonomy** out) {
+    if (!desc || !cfg || !out) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (desc->n_tax && (!desc->lin_off || !desc->lin_node || !desc->lin_rank)) {
+        set_error("lineage arrays missing"); return BLU_ERR_INVALID_ARG;
+    }
+    if (desc->n_tax >= 0xFFFFFFFFull) { set_error("n_tax must be < 2^32 - 1"); return BLU_ERR_INVALID_ARG; }
+    Backbone bb;
+    int rc = make_backbone(*cfg, &bb);
+    if (rc != BLU_OK) return rc;
+
+    auto* tax = new blu_taxonomy();
+    tax->device = device;
+    tax->cfg = *cfg;
+    tax->n_tax = desc->n_tax;
+
+    // canonical rank codes
+    static const char* letters[9] = {"u", "d", "k", "p", "c", "o", "f", "g", "s"};
+    static const char* fulls[9] = {"undefined", "domain", "kingdom", "phylum", "class", "order", "family", "genus", "species"};
+    for (int k = 0; k < 9; ++k) tax->ranks.push_back({letters[k], fulls[k]});
+    std::vector<uint16_t> code_of(desc->n_ranks);
+    std::map<std::string, uint16_t> other_codes;
+    for (uint32_t r = 0; r < desc->n_ranks; ++r) {
+        std::string other;
+        uint16_t k = parse_rank(desc->rank_names[r], &other);
+        if (k < K_FIRST_OTHER) { code_of[r] = k; continue; }
+        auto it = other_codes.find(other);
+        if (it == other_codes.end()) {
+            if (tax->ranks.size() >= BLU_MAR_NEVER_EQUAL) { delete tax; set_error("too many rank names"); return BLU_ERR_INVALID_ARG; }
+            it = other_codes.emplace(other, (uint16_t)tax->ranks.size()).first;
+            tax->ranks.push_back({other, other});
+        }
+        code_of[r] = it->second;
+    }
+
+    // depth scan
+    uint32_t max_depth = 0;
+    for (uint64_t t = 0; t < desc->n_tax; ++t) {
+        if (desc->lin_off[t + 1] < desc->lin_off[t]) { delete tax; set_error("lin_off not monotone at %llu", (unsigned long long)t); return BLU_ERR_INVALID_ARG; }
+        uint64_t len = desc->lin_off[t + 1] - desc->lin_off[t];
+        if (len > BLU_MAX_DEPTH) { delete tax; set_error("lineage of row %llu has %llu levels (max %u)", (unsigned long long)t, (unsigned long long)len, BLU_MAX_DEPTH); return BLU_ERR_DEPTH; }
+        max_depth = std::max<uint32_t>(max_depth, (uint32_t)len);
+    }
+    tax->max_depth = max_depth;
+    tax->stride = ((max_depth + 1 + 15) / 16) * 16;
+    if (tax->stride < 16) tax->stride = 16;
+    tax->sc = ((std::max<uint32_t>(max_depth, 1) + 15) / 16) * 16;
+
+    // shapes + lineage rows
+    std::map<std::vector<uint16_t>, uint32_t> shape_ids;
+    std::vector<std::vector<uint16_t>> shapes;
+    tax->h_lin.assign((size_t)desc->n_tax * tax->stride, 0u);
+    std::vector<uint16_t> seq;
+    for (uint64_t t = 0; t < desc->n_tax; ++t) {
+        uint64_t o = desc->lin_off[t];
+        uint32_t len = (uint32_t)(desc->lin_off[t + 1] - o);
+        uint32_t* row = &tax->h_lin[(size_t)t * tax->stride];
+        bool bad = (desc->bad && desc->bad[t]) || len == 0;  // "" fails parse_taxonomy too (blast_result.rs:65-67)
+        if (bad) { row[0] = 0; continue; }
+        seq.resize(len);
+        for (uint32_t j = 0; j < len; ++j) {
+            uint16_t rk = desc->lin_rank[o + j];
+            if (rk >= desc->n_ranks) { delete tax; set_error("lin_rank out of range at row %llu", (unsigned long long)t); return BLU_ERR_INVALID_ARG; }
+            seq[j] = code_of[rk];
+            row[1 + j] = desc->lin_node[o + j];
+        }
+        auto it = shape_ids.find(seq);
+        if (it == shape_ids.end()) {
+            if (shapes.size() >= (1u << 24)) { delete tax; set_error("too many lineage shapes"); return BLU_ERR_INVALID_ARG; }
+            it = shape_ids.emplace(seq, (uint32_t)shapes.size()).first;
+            shapes.push_back(seq);
+        }
+        row[0] = len | (it->second << 8);
+    }
+    tax->n_shapes = (uint32_t)shapes.size();
+    size_t nsh = std::max<size_t>(shapes.size(), 1);
+    tax->h_cut.assign(nsh * tax->sc, 0.0);
+    tax->h_codes.assign(nsh * tax->sc, 0u);
+    tax->h_isdef.assign(nsh * tax->sc, 0);
+    for (size_t s = 0; s < shapes.size(); ++s) {
+        const auto& sq = shapes[s];
+        double* cut = &tax->h_cut[s * tax->sc];
+        uint8_t* isdef = &tax->h_isdef[s * tax->sc];
+        interpolate_shape(bb, sq.data(), (int)sq.size(), cut, isdef);
+        for (size_t j = 0; j < sq.size(); ++j) {
+            // max_allowed_rank of level j (build_blast_consensus_identity.rs:22-30): DefaultRank(rank) -> rank;
+            // NonDefaultRank(name) -> Other(name), which equals a parsed rank only when that rank is itself Other.
+            uint32_t mar = isdef[j] ? sq[j] : (sq[j] >= K_FIRST_OTHER ? sq[j] : BLU_MAR_NEVER_EQUAL);
+            tax->h_codes[s * tax->sc + j] = (uint32_t)sq[j] | (mar << 16);
+        }
+    }
+    if (desc->taxid) {
+        tax->taxid_row.reserve((size_t)desc->n_tax * 2);
+        // polars left join on a table with duplicate keys would duplicate rows; blutils DBs have unique taxids.
+        for (uint64_t t = 0; t < desc->n_tax; ++t) tax->taxid_row.emplace(desc->taxid[t], (uint32_t)t);
+    }
+
+    if (device >= 0) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+            delete tax; set_error("no HIP device available (this engine has no CPU fallback)"); return BLU_ERR_NO_DEVICE;
+        }
+        if (device >= ndev) { delete tax; set_error("device %d out of range (%d devices)", device, ndev); return BLU_ERR_INVALID_ARG; }
+        hipError_t e = hipSetDevice(device);
+        hipDeviceProp_t prop;
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+        if (e == hipSuccess) tax->num_cus = prop.multiProcessorCount;
+        size_t b_lin = std::max<size_t>(tax->h_lin.size(), 16) * sizeof(uint32_t);
+        size_t b_cut = tax->h_cut.size() * sizeof(double);
+        size_t b_codes = tax->h_codes.size() * sizeof(uint32_t);
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lin, b_lin);
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_cut, b_cut);
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_codes, b_codes);
+        if (e == hipSuccess && !tax->h_lin.empty()) e = hipMemcpy(tax->d_lin, tax->h_lin.data(), tax->h_lin.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(tax->d_cut, tax->h_cut.data(), b_cut, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(tax->d_codes, tax->h_codes.data(), b_codes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("HIP error while uploading the taxonomy: %s", hipGetErrorString(e));
+            blu_taxonomy_destroy(tax);
+            return BLU_ERR_HIP;
+        }
+        tax->device_bytes = b_lin + b_cut + b_codes;
+    }
+    *out = tax;
+    return BLU_OK;
+}
+
+void blu_taxonomy_destroy(blu_taxonomy* tax) {
+    if (!tax) return;
+    if (tax->device >= 0) {
+        (void)hipSetDevice(tax->device);
+        if (tax->d_lin) (void)hipFree(tax->d_lin);
+        if (tax->d_cut) (void)hipFree(tax->d_cut);
+        if (tax->d_codes) (void)hipFree(tax->d_codes);
+    }
+    delete tax;
+}
+
+uint64_t blu_taxonomy_n_tax(const blu_taxonomy* tax) { return tax ? tax->n_tax : 0; }
+uint32_t blu_taxonomy_n_shapes(const blu_taxonomy* tax) { return tax ? tax->n_shapes : 0; }
+uint32_t blu_taxonomy_n_rank_codes(const blu_taxonomy* tax) { return tax ? (uint32_t)tax->ranks.size() : 0; }
+uint32_t blu_taxonomy_max_depth(const blu_taxonomy* tax) { return tax ? tax->max_depth : 0; }
+uint64_t blu_taxonomy_device_bytes(const blu_taxonomy* tax) { return tax ? tax->device_bytes : 0; }
+
+const char* blu_taxonomy_rank_name(const blu_taxonomy* tax, uint32_t rank_code, int serde) {
+    if (!tax || rank_code >= tax->ranks.size()) return nullptr;
+    return serde ? tax->ranks[rank_code].serde.c_str() : tax->ranks[rank_code].display.c_str();
+}
+
+int32_t blu_taxonomy_row_cutoffs(const blu_taxonomy* tax, uint64_t tax_row, uint32_t cap, double* cutoff,
+                                 uint8_t* is_default, uint16_t* rank_code) {
+    if (!tax || tax_row >= tax->n_tax) return -1;
+    uint32_t hdr = tax->h_lin[(size_t)tax_row * tax->stride];
+    uint32_t len = hdr & 0xFF, shape = hdr >> 8;
+    for (uint32_t j = 0; j < len && j < cap; ++j) {
+        size_t k = (size_t)shape * tax->sc + j;
+        if (cutoff) cutoff[j] = tax->h_cut[k];
+        if (is_default) is_default[j] = tax->h_isdef[k];
+        if (rank_code) rank_code[j] = (uint16_t)(tax->h_codes[k] & 0xFFFF);
+    }
+    return (int32_t)len;
+}
+
+int blu_taxonomy_lookup(const blu_taxonomy* tax, const int64_t* taxid, uint64_t n, uint32_t* out_row) {
+    if (!tax || (n && (!taxid || !out_row))) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    if (tax->taxid_row.empty() && tax->n_tax) { set_error("taxonomy was created without taxids"); return BLU_ERR_INVALID_ARG; }
+    for (uint64_t i = 0; i < n; ++i) {
+        auto it = tax->taxid_row.find(taxid[i]);
+        out_row[i] = it == tax->taxid_row.end() ? BLU_UNMATCHED_TAXID : it->second;
+    }
+    return BLU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+"""Host-side handle objects over the C ABI (include/blu_consensus.h).
+
+Mirrors the reference seam `build_consensus_identities`
+(core/src/use_cases/build_consensus_identities/mod.rs:40-47): a taxonomy + a
+cutoff configuration (Taxon, Option<CustomTaxon>) on one side, grouped hit rows
+on the other, a strategy, one result per query.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+RESULT_DTYPE = np.dtype([
+    ("status", "u1"), ("flags", "u1"), ("bean_index", "u1"), ("max_allowed_level", "u1"),
+    ("reached_rank", "<u2"), ("max_allowed_rank", "<u2"), ("identifier_node", "<u4"), ("ref_row", "<u4"),
+    ("level_mask", "<u8"), ("ident_used", "<f8"),
+])
+assert RESULT_DTYPE.itemsize == 32
+
+
+def _cutoff_config(taxon: str, custom: Optional[dict]) -> N.CutoffConfig:
+    cfg = N.CutoffConfig()
+    cfg.taxon = N.TAXON[taxon]
+    cfg.has_custom = 1 if custom is not None else 0
+    if custom is not None:
+        for i, k in enumerate(N.CUSTOM_FIELDS):
+            if custom.get(k) is not None:
+                cfg.custom[i] = int(custom[k])
+                cfg.custom_has[i] = 1
+    return cfg
+
+
+class Taxonomy:
+    """Device-resident taxonomy + per-shape cutoff tables (blu_taxonomy_create)."""
+
+    def __init__(self, lin_off, lin_node, lin_rank, rank_names: Sequence[str], taxon: str = "bacteria",
+                 custom: Optional[dict] = None, device: int = 0, taxid=None, bad=None):
+        L = N.lib()
+        self.lin_off = np.ascontiguousarray(lin_off, dtype=np.uint64)
+        self.lin_node = np.ascontiguousarray(lin_node, dtype=np.uint32)
+        self.lin_rank = np.ascontiguousarray(lin_rank, dtype=np.uint16)
+        self.rank_names = list(rank_names)
+        self.taxon, self.custom, self.device = taxon, custom, device
+        names = [s.encode() for s in self.rank_names]
+        arr = (C.c_char_p * max(1, len(names)))(*names)
+        desc = N.TaxonomyDesc()
+        desc.n_tax = len(self.lin_off) - 1
+        desc.lin_off = self.lin_off.ctypes.data
+        desc.lin_node = self.lin_node.ctypes.data
+        desc.lin_rank = self.lin_rank.ctypes.data
+        desc.n_ranks = len(names)
+        desc.rank_names = C.cast(arr, C.c_void_p)
+        self._taxid = None
+        if taxid is not None:
+            self._taxid = np.ascontiguousarray(taxid, dtype=np.int64)
+            desc.taxid = self._taxid.ctypes.data
+        if bad is not None:
+            self._bad = np.ascontiguousarray(bad, dtype=np.uint8)
+            desc.bad = self._bad.ctypes.data
+        cfg = _cutoff_config(taxon, custom)
+        h = C.c_void_p()
+        rc = L.blu_taxonomy_create(C.byref(desc), C.byref(cfg), device, C.byref(h))
+        if rc != N.BLU_OK:
+            raise N.BluError(rc, "blu_taxonomy_create")
+        self._h = h
+
+    # -- introspection -------------------------------------------------------
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def n_tax(self) -> int:
+        return N.lib().blu_taxonomy_n_tax(self._h)
+
+    @property
+    def n_shapes(self) -> int:
+        return N.lib().blu_taxonomy_n_shapes(self._h)
+
+    @property
+    def max_depth(self) -> int:
+        return N.lib().blu_taxonomy_max_depth(self._h)
+
+    @property
+    def device_bytes(self) -> int:
+        return N.lib().blu_taxonomy_device_bytes(self._h)
+
+    def rank_name(self, code: int, serde: bool = False) -> str:
+        p = N.lib().blu_taxonomy_rank_name(self._h, int(code), 1 if serde else 0)
+        if p is None:
+            raise IndexError(code)
+        return p.decode()
+
+    def row_cutoffs(self, row: int):
+        cut = np.zeros(64, dtype=np.float64)
+        isdef = np.zeros(64, dtype=np.uint8)
+        codes = np.zeros(64, dtype=np.uint16)
+        n = N.lib().blu_taxonomy_row_cutoffs(self._h, int(row), 64, cut.ctypes.data, isdef.ctypes.data, codes.ctypes.data)
+        if n < 0:
+            raise IndexError(row)
+        return cut[:n], isdef[:n].astype(bool), codes[:n]
+
+    def lookup(self, taxids) -> np.ndarray:
+        t = np.ascontiguousarray(taxids, dtype=np.int64)
+        out = np.zeros(len(t), dtype=np.uint32)
+        rc = N.lib().blu_taxonomy_lookup(self._h, t.ctypes.data, len(t), out.ctypes.data)
+        if rc != N.BLU_OK:
+            raise N.BluError(rc, "blu_taxonomy_lookup")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            N.lib().blu_taxonomy_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def run_consensus_host(tax: Taxonomy, seg_off, bitscore, tax_row, pident, align_len, acc_rank,
+                       strategy: str = "relaxed") -> np.ndarray:
+    """Host buffers in, host records out; the library stages them over PCIe."""
+    seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
+    bs = np.ascontiguousarray(bitscore, dtype=np.int32)
+    tx = np.ascontiguousarray(tax_row)
+    tx = tx.view(np.uint32) if tx.dtype == np.int32 else np.ascontiguousarray(tx, dtype=np.uint32)
+    pid = np.ascontiguousarray(pident, dtype=np.float64)
+    aln = np.ascontiguousarray(align_len, dtype=np.int32)
+    ac = np.ascontiguousarray(acc_rank)
+    ac = ac.view(np.uint32) if ac.dtype == np.int32 else np.ascontiguousarray(ac, dtype=np.uint32)
+    nq = len(seg) - 1
+    nh = int(seg[-1])
+    assert len(bs) == nh and len(tx) == nh and len(pid) == nh and len(aln) == nh and len(ac) == nh
+    hits = N.Hits(bs.ctypes.data, tx.ctypes.data, pid.ctypes.data, aln.ctypes.data, ac.ctypes.data, seg.ctypes.data,
+                  nh, nq, 0, 0)
+    params = N.RunParams(N.STRATEGY[strategy], 0, None)
+    out = np.zeros(nq, dtype=RESULT_DTYPE)
+    rc = N.lib().blu_consensus_run(tax.handle, C.byref(hits), C.byref(params), out.ctypes.data)
+    if rc != N.BLU_OK:
+        raise N.BluError(rc, "blu_consensus_run")
+    return out
+
+
+def run_consensus_device(tax: Taxonomy, hits: dict, out, strategy: str = "relaxed", stream: Optional[int] = None):
+    """torch CUDA tensors in (`hits` keys: seg_off bitscore tax_row pident align_len acc_rank), records into the
+    uint8 CUDA tensor `out` of 32 * n_queries bytes.  Asynchronous on `stream` (default: torch's current stream)."""
+    import torch
+
+    nq = hits["seg_off"].numel() - 1
+    nh = hits["bitscore"].numel()
+    for k, dt in (("seg_off", torch.int64), ("bitscore", torch.int32), ("tax_row", torch.int32),
+                  ("pident", torch.float64), ("align_len", torch.int32), ("acc_rank", torch.int32)):
+        t = hits[k]
+        assert t.is_cuda and t.is_contiguous() and t.dtype == dt, (k, t.dtype, t.device)
+    assert out.is_cuda and out.is_contiguous() and out.numel() * out.element_size() >= 32 * nq
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    h = N.Hits(hits["bitscore"].data_ptr(), hits["tax_row"].data_ptr(), hits["pident"].data_ptr(),
+               hits["align_len"].data_ptr(), hits["acc_rank"].data_ptr(), hits["seg_off"].data_ptr(), nh, nq, 1, 0)
+    params = N.RunParams(N.STRATEGY[strategy], 0, stream)
+    rc = N.lib().blu_consensus_run(tax.handle, C.byref(h), C.byref(params), out.data_ptr())
+    if rc != N.BLU_OK:
+        raise N.BluError(rc, "blu_consensus_run")
+
+
+def records_from_tensor(out) -> np.ndarray:
+    """uint8 CUDA/CPU tensor -> numpy structured array of blu_result."""
+    return out.detach().cpu().numpy().view(np.uint8).reshape(-1)[: (out.numel() * out.element_size()) // 32 * 32].view(RESULT_DTYPE)
+
+
+def last_launch():
+    name = C.create_string_buffer(128)
+    grid, block = C.c_uint32(), C.c_uint32()
+    N.lib().blu_consensus_last_launch(name, 128, C.byref(grid), C.byref(block))
+    return name.value.decode(), grid.value, block.value

@@ -1,0 +1,186 @@
+/*
+ * blu_consensus.h — C ABI of the MI355X-native consensus engine.
+ *
+ * Drop-in boundary for blutils' per-query taxonomic consensus.  The reference
+ * (pure Rust, no FFI of its own) exposes this path as
+ *
+ *   core/src/use_cases/build_consensus_identities/mod.rs:40-47
+ *     pub fn build_consensus_identities(blast_output, taxonomies_file, taxon,
+ *                                       strategy, use_taxid, custom_taxon_values)
+ *   core/src/use_cases/build_consensus_identities/find_single_query_consensus.rs:17-23
+ *     fn find_single_query_consensus(query, result: Vec<BlastResultRow>, taxon,
+ *                                    strategy, custom_taxon_values)
+ *
+ * A Rust shim replacing the rayon map at mod.rs:104-128 binds exactly the
+ * entry points below (see INTEGRATION.md for the `extern "C"` block).  Plain
+ * pointers and sizes only; no exceptions or aborts cross this boundary: every
+ * reference panic site becomes a per-query status (blu_status) or a call-level
+ * error code (blu_error).
+ */
+#ifndef BLU_CONSENSUS_H
+#define BLU_CONSENSUS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLU_ABI_VERSION 1u
+#define BLU_UNMATCHED_TAXID 0xFFFFFFFFu /* hit whose subject_taxid is not in the taxonomy (left join miss, mod.rs:72-76) */
+#define BLU_MAX_DEPTH 64u               /* level_mask is 64 bits wide */
+#define BLU_NONE_U8 0xFFu
+#define BLU_NONE_U16 0xFFFFu
+#define BLU_MAR_NEVER_EQUAL 0xFFFEu     /* Other("k")/Other("u"): a default-letter rank outside the backbone */
+
+/* call-level error codes (return values) */
+enum blu_error {
+    BLU_OK = 0,
+    BLU_ERR_INVALID_ARG = 1,
+    BLU_ERR_NO_DEVICE = 2,      /* HIP runtime/device missing: the engine has no CPU fallback */
+    BLU_ERR_HIP = 3,
+    BLU_ERR_DEPTH = 4,          /* a lineage deeper than BLU_MAX_DEPTH */
+    BLU_ERR_CUSTOM_MISSING = 5, /* Taxon::Custom without values (domain/dtos/taxon.rs:117) */
+    BLU_ERR_ALLOC = 6,
+    BLU_ERR_IO = 7,
+    BLU_ERR_PARSE = 8
+};
+
+/* domain/dtos/taxon.rs:68-87 */
+enum blu_taxon { BLU_TAXON_FUNGI = 0, BLU_TAXON_BACTERIA = 1, BLU_TAXON_EUKARYOTES = 2, BLU_TAXON_CUSTOM = 3 };
+/* domain/dtos/consensus_strategy.rs:4-10 */
+enum blu_strategy { BLU_CAUTIOUS = 0, BLU_RELAXED = 1 };
+
+/* Taxon + Option<CustomTaxon> (domain/dtos/taxon.rs:16-25): value order is
+ * domain, kingdom, phylum, class, order, family, genus, species. */
+typedef struct blu_cutoff_config {
+    int32_t taxon;         /* enum blu_taxon */
+    int32_t has_custom;    /* Option<CustomTaxon> is Some */
+    int16_t custom[8];
+    uint8_t custom_has[8]; /* the six middle ranks are Option<i16>; unwrap_or(0) when 0 */
+} blu_cutoff_config;
+
+/* Taxonomy table: one row per taxid of the blutils DB (a3), lineage as CSR of
+ * interned (rank, identifier) node ids, root -> leaf (a6).  rank_names[] are
+ * the rank strings as they appear in lineages ("d", "clade", "species-group"
+ * ...); the library applies LinnaeanRank::from_str (linnaean_ranks.rs:52-72).
+ * lin_node must be interned on the CANONICAL pair (Display(rank), identifier),
+ * the key the reference compares levels on (find_multi_taxa_consensus.rs:150-159). */
+typedef struct blu_taxonomy_desc {
+    uint64_t n_tax;
+    const int64_t* taxid;          /* [n_tax] or NULL */
+    const uint64_t* lin_off;       /* [n_tax + 1] */
+    const uint32_t* lin_node;      /* [lin_off[n_tax]] */
+    const uint16_t* lin_rank;      /* [lin_off[n_tax]] index into rank_names */
+    uint32_t n_ranks;
+    const char* const* rank_names; /* [n_ranks] */
+    const uint8_t* bad;            /* [n_tax] or NULL; 1 = lineage string fails parse_taxonomy (blast_result.rs:109-114) */
+} blu_taxonomy_desc;
+
+typedef struct blu_taxonomy blu_taxonomy; /* opaque; owns the device copy */
+
+/* Hit table, SoA, rows grouped by query with in-query FILE ORDER preserved
+ * (stable-sort ties depend on it, find_multi_taxa_consensus.rs:39-68).  Only
+ * the columns the reference semantics read; e_value and the six
+ * coordinate columns are dead inputs and are not part of the layout. */
+typedef struct blu_hits {
+    const int32_t* bitscore;   /* [n_hits] bit_score truncated toward zero to integer (mod.rs:184) */
+    const uint32_t* tax_row;   /* [n_hits] row in the taxonomy table or BLU_UNMATCHED_TAXID */
+    const double* pident;      /* [n_hits] perc_identity */
+    const int32_t* align_len;  /* [n_hits] */
+    const uint32_t* acc_rank;  /* [n_hits] order-preserving rank of subject_accession (bytewise String::cmp) */
+    const uint64_t* seg_off;   /* [n_queries + 1] row offsets, seg_off[0] = 0, seg_off[n_queries] = n_hits */
+    uint64_t n_hits;           /* < 2^32 per call */
+    uint64_t n_queries;
+    int32_t on_device;         /* 1: every pointer (and `out`) is a device pointer on the handle's GPU;
+                                  0: host pointers, the library stages them over PCIe */
+    int32_t reserved;
+} blu_hits;
+
+typedef struct blu_run_params {
+    int32_t strategy; /* enum blu_strategy */
+    int32_t flags;    /* reserved, 0 */
+    void* stream;     /* hipStream_t to launch on (NULL = default stream) */
+} blu_run_params;
+
+/* per-query status: 0/1 are the two reference outcomes with a taxon, 2 is
+ * NoConsensusFound, >= 16 are the reference's panic sites */
+enum blu_status {
+    BLU_ST_CONSENSUS_MULTI = 0,   /* find_multi_taxa_consensus outcome */
+    BLU_ST_CONSENSUS_SINGLE = 1,  /* single top-score hit (find_single_query_consensus.rs:74-150) */
+    BLU_ST_NO_HITS = 2,           /* empty segment: NoConsensusFound (mod.rs:107-113) */
+    BLU_ST_ERR_UNMATCHED_TAXID = 16, /* top-group row whose taxid is not in the DB (find_single_query_consensus.rs:58-60) */
+    BLU_ST_ERR_BAD_LINEAGE = 17,     /* top-group row whose lineage fails parse_taxonomy (blast_result.rs:109-114) */
+    BLU_ST_ERR_ROOT_DISAGREE = 18,   /* disagreement at level 0: `index - 1` underflow (find_multi_taxa_consensus.rs:181) */
+    BLU_ST_ERR_SINGLE_BELOW_CUTOFFS = 19, /* single hit below every cutoff (find_single_query_consensus.rs:113-119) */
+    BLU_ST_ERR_BAD_PIDENT = 20       /* NaN perc_identity in the top group: comparator/unwrap behaviour not restated */
+};
+
+#define BLU_FLAG_MUTATED 0x01u /* TaxonomyBean.mutated (build_blast_consensus_identity.rs:35-37) */
+#define BLU_FLAG_AGREE 0x02u   /* every examined level agreed: taxonomy = whole cutoff-filtered reference lineage */
+
+/* One 32-byte record per query.  Strings (taxonomy, consensus beans) are
+ * rebuilt on the host from (ref_row, level_mask, bean_index). */
+typedef struct blu_result {
+    uint8_t status;            /* enum blu_status */
+    uint8_t flags;             /* BLU_FLAG_* */
+    uint8_t bean_index;        /* index into the reference lineage passed to build_blast_consensus_identity */
+    uint8_t max_allowed_level; /* level of the reference lineage whose rank is max_allowed_rank; BLU_NONE_U8 = None */
+    uint16_t reached_rank;     /* canonical rank code of the final element (blu_taxonomy_rank_name) */
+    uint16_t max_allowed_rank; /* canonical rank code, BLU_MAR_NEVER_EQUAL, or BLU_NONE_U16 */
+    uint32_t identifier_node;  /* interned node id of the final element: TaxonomyBean.identifier */
+    uint32_t ref_row;          /* absolute hit row of the reference row R: perc_identity, bit_score, lineage */
+    uint64_t level_mask;       /* bit j set = level j of R's lineage is in `taxonomy` */
+    double ident_used;         /* identity tested against the cutoffs (R's pident, or the group max on disagreement) */
+} blu_result;
+
+/* -------------------------------------------------------------------------- */
+
+uint32_t blu_abi_version(void);
+
+/* Copies the last error message of the calling thread into buf (NUL-terminated,
+ * truncated to len); returns the message length. */
+size_t blu_last_error(char* buf, size_t len);
+
+/* Builds the device-resident taxonomy: lineage rows, rank-sequence shapes and
+ * the per-shape f64 cutoff tables (InterpolatedIdentity::interpolate_identities,
+ * linnaean_ranks.rs:220-383; Taxon::get_taxon_cutoff, taxon.rs:104-185).
+ * device >= 0: HIP device ordinal.  device == -1: host-only handle (cutoff and
+ * shape queries work, blu_consensus_run refuses) — used by CPU-side tests.
+ * Caller keeps ownership of desc arrays; they may be freed after the call. */
+int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* cfg, int device,
+                        blu_taxonomy** out);
+void blu_taxonomy_destroy(blu_taxonomy* tax);
+
+/* Introspection used by the host-side renderer and by tests. */
+uint64_t blu_taxonomy_n_tax(const blu_taxonomy* tax);
+uint32_t blu_taxonomy_n_shapes(const blu_taxonomy* tax);
+uint32_t blu_taxonomy_n_rank_codes(const blu_taxonomy* tax);
+uint32_t blu_taxonomy_max_depth(const blu_taxonomy* tax);
+uint64_t blu_taxonomy_device_bytes(const blu_taxonomy* tax);
+/* canonical rank code -> Display string (linnaean_ranks.rs:74-89); serde!=0 gives
+ * the serde name ("species", raw string for Other; linnaean_ranks.rs:14-29). */
+const char* blu_taxonomy_rank_name(const blu_taxonomy* tax, uint32_t rank_code, int serde);
+/* cutoffs of one taxonomy row: writes up to cap entries, returns the lineage length
+ * (0 for a bad lineage, -1 for an invalid row). is_default[j]=1: level j mapped to a
+ * DefaultRank of the backbone.  rank_code[j]: canonical code of level j. */
+int32_t blu_taxonomy_row_cutoffs(const blu_taxonomy* tax, uint64_t tax_row, uint32_t cap, double* cutoff,
+                                 uint8_t* is_default, uint16_t* rank_code);
+/* taxid -> taxonomy row (BLU_UNMATCHED_TAXID when absent); needs desc.taxid at create. */
+int blu_taxonomy_lookup(const blu_taxonomy* tax, const int64_t* taxid, uint64_t n, uint32_t* out_row);
+
+/* The hot path: one blu_result per query.  `out` has n_queries records, on the
+ * device when hits->on_device, else on the host.  Asynchronous on
+ * params->stream when on_device (no host sync inside); synchronous otherwise. */
+int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_run_params* params,
+                      blu_result* out);
+
+/* Name of the dominant kernel and its launch geometry for the last run on this
+ * thread (for profiles/ bookkeeping). */
+int blu_consensus_last_launch(char* kernel_name, size_t len, uint32_t* grid, uint32_t* block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLU_CONSENSUS_H */

@@ -732,3 +732,56 @@ int32_t blu_oracle_rank_serde(const char* rank, char* buf, int32_t buflen) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Helpers for the cpu_baseline leg of bench.py: materialise the string side of
+// a synthetic table (blutils DB lineage grammar `rank__identifier;...`,
+// build_taxonomy_database.rs:406-465; accession `NR_%010u.1`) without a Python
+// loop over millions of rows.  Data preparation only — not timed.
+// ---------------------------------------------------------------------------
+extern "C" {
+
+struct blu_oracle_strtab {
+    std::vector<std::string> s;
+    std::vector<const char*> p;
+};
+
+blu_oracle_strtab* blu_oracle_lineage_strings(uint64_t n_tax, const uint64_t* lin_off, const uint32_t* lin_node,
+                                              const uint16_t* lin_rank, const char* const* rank_names,
+                                              const char* id_prefix) {
+    auto* t = new blu_oracle_strtab();
+    t->s.resize(n_tax);
+    t->p.resize(n_tax ? n_tax : 1);
+    char buf[32];
+    for (uint64_t i = 0; i < n_tax; ++i) {
+        std::string& o = t->s[i];
+        for (uint64_t k = lin_off[i]; k < lin_off[i + 1]; ++k) {
+            if (k > lin_off[i]) o.push_back(';');
+            o += rank_names[lin_rank[k]];
+            o += "__";
+            o += id_prefix;
+            std::snprintf(buf, sizeof buf, "%u", lin_node[k]);
+            o += buf;
+        }
+    }
+    for (uint64_t i = 0; i < n_tax; ++i) t->p[i] = t->s[i].c_str();
+    return t;
+}
+
+blu_oracle_strtab* blu_oracle_accession_strings(uint64_t n, const uint32_t* acc_rank) {
+    auto* t = new blu_oracle_strtab();
+    t->s.resize(n);
+    t->p.resize(n ? n : 1);
+    char buf[32];
+    for (uint64_t i = 0; i < n; ++i) {
+        std::snprintf(buf, sizeof buf, "NR_%010u.1", acc_rank[i]);
+        t->s[i] = buf;
+    }
+    for (uint64_t i = 0; i < n; ++i) t->p[i] = t->s[i].c_str();
+    return t;
+}
+
+const char* const* blu_oracle_strtab_ptr(const blu_oracle_strtab* t) { return t->p.data(); }
+void blu_oracle_strtab_free(blu_oracle_strtab* t) { delete t; }
+
+}  // extern "C"

@@ -230,3 +230,101 @@ def rank_serde(rank: str) -> str:
     buf = C.create_string_buffer(256)
     lib().blu_oracle_rank_serde(rank.encode(), buf, 256)
     return buf.value.decode()
+
+
+# ---------------------------------------------------------------------------
+# Columnar oracle (oracle/blu_oracle_columnar.cpp): same semantics on the
+# interned SoA layout; records have the layout of include/blu_consensus.h.
+# ---------------------------------------------------------------------------
+RESULT_DTYPE = np.dtype([
+    ("status", "u1"), ("flags", "u1"), ("bean_index", "u1"), ("max_allowed_level", "u1"),
+    ("reached_rank", "<u2"), ("max_allowed_rank", "<u2"), ("identifier_node", "<u4"), ("ref_row", "<u4"),
+    ("level_mask", "<u8"), ("ident_used", "<f8"),
+])
+assert RESULT_DTYPE.itemsize == 32
+
+
+def columnar_run(lin_off, lin_node, lin_rank, rank_names, seg_off, bitscore, tax_row, pident, align_len, acc_rank,
+                 taxon="bacteria", strategy="relaxed", custom=None, bad=None, threads=1):
+    L = lib()
+    fn = L.blu_oracle_columnar_run
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lin_off = np.ascontiguousarray(lin_off, dtype=np.uint64)
+    lin_node = np.ascontiguousarray(lin_node, dtype=np.uint32)
+    lin_rank = np.ascontiguousarray(lin_rank, dtype=np.uint16)
+    seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
+    bs = np.ascontiguousarray(bitscore, dtype=np.int32)
+    tx = np.ascontiguousarray(tax_row).view(np.uint32) if np.asarray(tax_row).dtype == np.int32 else np.ascontiguousarray(tax_row, dtype=np.uint32)
+    pid = np.ascontiguousarray(pident, dtype=np.float64)
+    aln = np.ascontiguousarray(align_len, dtype=np.int32)
+    ac = np.ascontiguousarray(acc_rank).view(np.uint32) if np.asarray(acc_rank).dtype == np.int32 else np.ascontiguousarray(acc_rank, dtype=np.uint32)
+    names = StringTable(list(rank_names))
+    vals, has = _custom_arrays(custom)
+    badp = None
+    if bad is not None:
+        bad = np.ascontiguousarray(bad, dtype=np.uint8)
+        badp = bad.ctypes.data
+    nq = len(seg) - 1
+    out = np.zeros(nq, dtype=RESULT_DTYPE)
+    rc = fn(len(lin_off) - 1, lin_off.ctypes.data, lin_node.ctypes.data, lin_rank.ctypes.data, len(rank_names),
+            names.ptr, badp, TAXON[taxon], 1 if custom is not None else 0, C.cast(vals, C.c_void_p),
+            C.cast(has, C.c_void_p), nq, seg.ctypes.data, bs.ctypes.data, tx.ctypes.data, pid.ctypes.data,
+            aln.ctypes.data, ac.ctypes.data, STRATEGY[strategy], threads, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle panic status {rc}")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# bench.py cpu_baseline leg: the string-faithful oracle on a slice of a synthetic
+# SoA table.  String tables are built in C (data preparation, not timed).
+# ---------------------------------------------------------------------------
+def faithful_on_synthetic(lin_off, lin_node, lin_rank, rank_names, seg_off, bitscore, tax_row, pident, align_len,
+                          acc_rank, taxon="bacteria", strategy="relaxed", custom=None, threads=1, want_json=False):
+    """Returns (seconds spent inside blu_oracle_run, OracleRun).  Every row gets its own accession entry
+    (acc_idx = row), so no dictionary pass is needed."""
+    import time
+
+    L = lib()
+    L.blu_oracle_lineage_strings.restype = C.c_void_p
+    L.blu_oracle_lineage_strings.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
+    L.blu_oracle_accession_strings.restype = C.c_void_p
+    L.blu_oracle_accession_strings.argtypes = [C.c_uint64, C.c_void_p]
+    L.blu_oracle_strtab_ptr.restype = C.c_void_p
+    L.blu_oracle_strtab_ptr.argtypes = [C.c_void_p]
+    L.blu_oracle_strtab_free.argtypes = [C.c_void_p]
+    lin_off = np.ascontiguousarray(lin_off, dtype=np.uint64)
+    lin_node = np.ascontiguousarray(lin_node, dtype=np.uint32)
+    lin_rank = np.ascontiguousarray(lin_rank, dtype=np.uint16)
+    names = StringTable(list(rank_names))
+    seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
+    nq, nh = len(seg) - 1, int(seg[-1])
+    acc = np.ascontiguousarray(acc_rank)
+    acc = acc.view(np.uint32) if acc.dtype == np.int32 else np.ascontiguousarray(acc, dtype=np.uint32)
+    tr = np.ascontiguousarray(tax_row)
+    tr = tr.astype(np.int64) if tr.dtype == np.int32 else np.where(tr == 0xFFFFFFFF, -1, tr.astype(np.int64))
+    tr = np.ascontiguousarray(tr, dtype=np.int64)
+    pid = np.ascontiguousarray(pident, dtype=np.float64)
+    aln = np.ascontiguousarray(align_len, dtype=np.int64)
+    bsc = np.ascontiguousarray(bitscore, dtype=np.int64)
+    acc_idx = np.arange(nh, dtype=np.uint32)
+    lt = L.blu_oracle_lineage_strings(len(lin_off) - 1, lin_off.ctypes.data, lin_node.ctypes.data,
+                                      lin_rank.ctypes.data, names.ptr, b"n")
+    at = L.blu_oracle_accession_strings(nh, acc.ctypes.data)
+    try:
+        cfg = _make_cfg(taxon, strategy, custom, threads)
+        t0 = time.perf_counter()
+        h = L.blu_oracle_run(nq, seg.ctypes.data, acc_idx.ctypes.data, L.blu_oracle_strtab_ptr(at), tr.ctypes.data,
+                             L.blu_oracle_strtab_ptr(lt), None, pid.ctypes.data, aln.ctypes.data, bsc.ctypes.data,
+                             C.byref(cfg))
+        dt = time.perf_counter() - t0
+        run_ = OracleRun(h, nq)
+        if want_json:
+            run_._json = run_.results()
+    finally:
+        L.blu_oracle_strtab_free(lt)
+        L.blu_oracle_strtab_free(at)
+    return dt, run_

@@ -1,0 +1,115 @@
+"""CPU-side checks of the product library: it loads, exports every symbol of include/blu_consensus.h,
+refuses to compute without a GPU, and its per-shape cutoff tables (host C++ in blutils_amd/csrc/taxonomy.cpp)
+equal the oracle's restatement of InterpolatedIdentity::interpolate_identities."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from blutils_amd import _native as N
+from blutils_amd import engine, synth
+from oracle import oracle as orc
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "blu_consensus.h")).read()
+    declared = set(re.findall(r"\b(blu_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(N.EXPORTS)
+    L = N.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.blu_abi_version() == 1
+
+
+def test_result_record_layout():
+    assert engine.RESULT_DTYPE.itemsize == 32
+    assert [engine.RESULT_DTYPE.fields[k][1] for k in engine.RESULT_DTYPE.names] == [0, 1, 2, 3, 4, 6, 8, 12, 16, 24]
+
+
+def _host_tax(tax, taxon, custom=None):
+    return engine.Taxonomy(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, taxon=taxon, custom=custom,
+                           device=-1, taxid=tax.taxid)
+
+
+@pytest.mark.parametrize("taxon,custom", [("bacteria", None), ("fungi", None), ("eukaryotes", None),
+                                          ("custom", H.CUSTOM_16S), ("custom", {"domain": 55, "species": 98})])
+@pytest.mark.parametrize("deep", [False, True])
+def test_shape_cutoffs_match_oracle(taxon, custom, deep):
+    tax = synth.make_taxonomy(4000, 11, deep=deep)
+    t = _host_tax(tax, taxon, custom)
+    seen = {}
+    for row in range(tax.n):
+        a, b = int(tax.lin_off[row]), int(tax.lin_off[row + 1])
+        key = tuple(tax.lin_rank[a:b])
+        if key in seen:
+            continue
+        seen[key] = row
+        cut, isdef, codes = t.row_cutoffs(row)
+        ocut, oisdef = orc.interpolate([tax.rank_names[i] for i in key], taxon, custom)
+        np.testing.assert_array_equal(cut.view(np.uint64), ocut.view(np.uint64))   # bit-exact, NaN included
+        assert list(isdef) == list(oisdef)
+        for j, i in enumerate(key):
+            assert t.rank_name(codes[j]) == orc.rank_display(tax.rank_names[i])
+            assert t.rank_name(codes[j], serde=True) == orc.rank_serde(tax.rank_names[i])
+    assert t.n_shapes == len(seen) and len(seen) > (50 if deep else 10)
+
+
+def test_pathological_rank_sequences_match_oracle():
+    """duplicate ranks, leading/trailing non-default runs, one-element windows (NaN), mixed-case names."""
+    rng = np.random.default_rng(3)
+    names = ["d", "Kingdom", "p", "c", "o", "f", "g", "s", "clade", "no rank", "strain", "u", "Domain", "clade "]
+    seqs = [["clade"], ["clade", "d", "clade"], ["strain", "strain"], ["d", "d", "clade", "d"], ["u"], ["s", "clade", "d"]]
+    for _ in range(300):
+        n = int(rng.integers(1, 14))
+        seqs.append([names[int(i)] for i in rng.integers(0, len(names), n)])
+    off = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
+    rank = np.array([names.index(r) for s in seqs for r in s], dtype=np.uint16)
+    node = np.arange(len(rank), dtype=np.uint32)
+    for taxon, custom in (("bacteria", None), ("custom", H.CUSTOM_16S)):
+        t = engine.Taxonomy(off, node, rank, names, taxon=taxon, custom=custom, device=-1)
+        for i, s in enumerate(seqs):
+            cut, isdef, _ = t.row_cutoffs(i)
+            ocut, oisdef = orc.interpolate(s, taxon, custom)
+            np.testing.assert_array_equal(cut.view(np.uint64), ocut.view(np.uint64), err_msg=str(s))
+            assert list(isdef) == list(oisdef)
+
+
+def test_custom_taxon_without_values_is_an_error():
+    tax = synth.make_taxonomy(50, 1)
+    with pytest.raises(N.BluError) as e:
+        _host_tax(tax, "custom", None)
+    assert e.value.code == N.BLU_ERR_CUSTOM_MISSING      # taxon.rs:117 panic -> call-level error
+
+
+def test_too_deep_lineage_is_refused():
+    off = np.array([0, 65], dtype=np.uint64)
+    with pytest.raises(N.BluError) as e:
+        engine.Taxonomy(off, np.arange(65, dtype=np.uint32), np.zeros(65, dtype=np.uint16), ["clade"], device=-1)
+    assert e.value.code == N.BLU_ERR_DEPTH
+
+
+def test_taxid_lookup():
+    tax = synth.make_taxonomy(300, 2)
+    t = _host_tax(tax, "bacteria")
+    rows = t.lookup(np.array([tax.taxid[5], 999999999, tax.taxid[299]], dtype=np.int64))
+    assert rows.tolist() == [5, N.BLU_UNMATCHED_TAXID, 299]
+
+
+def test_no_cpu_fallback():
+    """Without a device the hot path must fail loudly, never compute on the host."""
+    tax = synth.make_taxonomy(100, 1)
+    hits = synth.make_hits(tax, 10, 2, 5).numpy()
+    t = _host_tax(tax, "bacteria")
+    with pytest.raises(N.BluError) as e:
+        engine.run_consensus_host(t, hits["seg_off"], hits["bitscore"], hits["tax_row"], hits["pident"],
+                                  hits["align_len"], hits["acc_rank"])
+    assert e.value.code == N.BLU_ERR_NO_DEVICE
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(N.BluError) as e2:
+            engine.Taxonomy(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, device=0)
+        assert e2.value.code == N.BLU_ERR_NO_DEVICE
