@@ -37,10 +37,19 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     if (hipSetDevice(tax->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", tax->device); return BLU_ERR_NO_DEVICE; }
 
     TaxDev td{tax->d_lin, tax->d_cut, tax->d_codes, tax->n_tax, tax->stride, tax->sc};
+    if (tax->ws_capacity < hits->n_queries || !tax->ws_count) {
+        // grows only when a larger table than any before arrives (first call): not graph-capturable
+        if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
+        if (!tax->ws_count && hipMalloc((void**)&tax->ws_count, 256) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return BLU_ERR_ALLOC; }
+        tax->ws_worklist = nullptr;
+        tax->ws_capacity = 0;
+        if (hipMalloc((void**)&tax->ws_worklist, (hits->n_queries + 64) * sizeof(uint32_t)) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return BLU_ERR_ALLOC; }
+        tax->ws_capacity = hits->n_queries;
+    }
     if (hits->on_device) {
         HitsDev hd{hits->bitscore, hits->tax_row, hits->pident, hits->align_len, hits->acc_rank, hits->seg_off,
                    hits->n_hits, hits->n_queries};
-        return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus);
+        return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count);
     }
 
     // host pointers: stage over PCIe, run, copy the records back (synchronous)
@@ -67,7 +76,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         HIP_TRY(hipMemcpyAsync(d_seg, hits->seg_off, (nq + 1) * 8, hipMemcpyHostToDevice, s));
         HitsDev hd{(const int32_t*)d_bs, (const uint32_t*)d_tax, (const double*)d_pid, (const int32_t*)d_aln,
                    (const uint32_t*)d_acc, (const uint64_t*)d_seg, hits->n_hits, hits->n_queries};
-        rc = launch_consensus(td, hd, params->strategy, (blu_result*)d_out, s, tax->device, tax->num_cus);
+        rc = launch_consensus(td, hd, params->strategy, (blu_result*)d_out, s, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count);
         if (rc != BLU_OK) goto done;
         HIP_TRY(hipMemcpyAsync(out, d_out, nq * sizeof(blu_result), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));

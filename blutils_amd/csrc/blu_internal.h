@@ -42,8 +42,9 @@ struct HitsDev {
 };
 
 // launch wrapper implemented in consensus_kernel.hip
+// worklist: n_queries uint32 slots; work_count: one uint32 (both device memory)
 int launch_consensus(const TaxDev& tax, const HitsDev& hits, int strategy, blu_result* out, void* stream,
-                     int device, int num_cus);
+                     int device, int num_cus, uint32_t* worklist, uint32_t* work_count);
 const char* consensus_kernel_name();
 void consensus_last_geometry(uint32_t* grid, uint32_t* block);
 
@@ -70,4 +71,9 @@ struct blu_taxonomy {
     double* d_cut = nullptr;
     uint32_t* d_codes = nullptr;
     uint64_t device_bytes = 0;
+    // per-handle scratch of the run call (worklist of long / overflowing queries); grown on demand,
+    // so one handle must not be used by two concurrent blu_consensus_run calls
+    mutable uint32_t* ws_worklist = nullptr;
+    mutable uint32_t* ws_count = nullptr;
+    mutable uint64_t ws_capacity = 0;
 };

@@ -300,6 +300,8 @@ void blu_taxonomy_destroy(blu_taxonomy* tax) {
         if (tax->d_lin) (void)hipFree(tax->d_lin);
         if (tax->d_cut) (void)hipFree(tax->d_cut);
         if (tax->d_codes) (void)hipFree(tax->d_codes);
+        if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
+        if (tax->ws_count) (void)hipFree(tax->ws_count);
     }
     delete tax;
 }

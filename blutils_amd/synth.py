@@ -289,7 +289,10 @@ def make_hits(tax: SynthTaxonomy, n_queries: int, seed: int, hits_per_query: Opt
     if "lo" not in tables or tables["lo"].device != dev:
         tables["lo"] = torch.from_numpy(tax.level_lo).to(dev)
         tables["hi"] = torch.from_numpy(tax.level_hi).to(dev)
-    lo_t, hi_t = tables["lo"], tables["hi"]
+        # k / 1000 as the correctly rounded double (= what parsing the 3-decimal text gives); the GPU's
+        # own f64 division is not correctly rounded, so the quotients come from a CPU-built table
+        tables["pid"] = torch.from_numpy(np.arange(0, 100001, dtype=np.float64) / 1000.0).to(dev)
+    lo_t, hi_t, pid_t = tables["lo"], tables["hi"], tables["pid"]
     # LCA-level categorical (per mille): root 5, d 10, k 15, p 20, c 50, o 100, f 150, g 300, s 350
     lvl_thr = torch.tensor([5, 15, 30, 50, 100, 200, 350, 650], dtype=torch.int64, device=dev)
     # geometric(0.35) top-group size: P(size > j) = 0.65^j, as exact integer thresholds on 2^62
@@ -339,7 +342,7 @@ def make_hits(tax: SynthTaxonomy, n_queries: int, seed: int, hits_per_query: Opt
         taxr = torch.where(miss, torch.full_like(subj, 0xFFFFFFFF), subj)
         out.bitscore[r0:r1] = bs.to(torch.int32)
         out.tax_row[r0:r1] = torch.where(taxr >= (1 << 31), taxr - (1 << 32), taxr).to(torch.int32)
-        out.pident[r0:r1] = pid_m.to(torch.float64) / 1000.0
+        out.pident[r0:r1] = pid_t[pid_m]
         out.align_len[r0:r1] = aln.to(torch.int32)
         out.acc_rank[r0:r1] = torch.where(acc >= (1 << 31), acc - (1 << 32), acc).to(torch.int32)
     return out
