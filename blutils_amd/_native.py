@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libblu_consensus.so")
+# BLU_CONSENSUS_LIB: load an experimental build of the same ABI (kernel A/B experiments under scripts/)
+LIB_PATH = os.environ.get("BLU_CONSENSUS_LIB") or os.path.join(_HERE, "lib", "libblu_consensus.so")
 
 # every symbol include/blu_consensus.h declares
 EXPORTS = (

@@ -34,8 +34,12 @@ namespace blu {
 #define WAVE 64
 #define BLOCK_A 256
 #define WAVES_A (BLOCK_A / WAVE)
+#ifndef BATCH
 #define BATCH 4            // queries in flight per wave in phase 1
-#define LIST_CAP 256       // top-group entries per wave task (64 queries; mean ~183, sigma ~18 at geometric(0.35) groups)
+#endif
+#ifndef LIST_CAP
+#define LIST_CAP 224       // top-group entries per wave task (64 queries; mean ~183, sigma ~18 at geometric(0.35) groups)
+#endif
 #define ENTRY_BYTES 24
 
 // ---- cross-lane helpers -----------------------------------------------------
@@ -135,116 +139,30 @@ __device__ __forceinline__ bool key_better(uint32_t len, double pid, int aln, ui
 // Kernel A
 // ===============================================================================
 struct Entry {            // one top-group row in LDS, 24 bytes
-    uint32_t tax, aln, acc, pos;
+    uint32_t tax, aln, acc, pq;   // pq = position in the segment | query-in-task << 8
     double pid;
 };
 static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 
-#define META_EMPTY 0x40000000u
 #define META_SLOW 0x80000000u
+#define NO_REF 0xFFFFFFFFu
 
-// phase 2: one lane = one query.  Everything below is per-lane serial code over the
-// lane's own top group (k entries starting at list[off]).
-template <int STRAT>
-__device__ __forceinline__ void finish_query(const TaxDev& t, blu_result* out, uint64_t q, uint32_t row0,
-                                             const Entry* list, uint32_t k) {
-    // parse errors first, in file order (find_single_query_consensus.rs:51-64)
-    for (uint32_t e = 0; e < k; ++e) {
-        const uint32_t tax = list[e].tax;
-        if (tax >= t.n_tax) { store_status(out, q, BLU_ST_ERR_UNMATCHED_TAXID, row0 + list[e].pos); return; }
-        if ((t.lin[(uint64_t)tax * t.stride] & 0xFF) == 0) { store_status(out, q, BLU_ST_ERR_BAD_LINEAGE, row0 + list[e].pos); return; }
-    }
-    for (uint32_t e = 0; e < k; ++e) {
-        const double p = list[e].pid;
-        if (p != p) { store_status(out, q, BLU_ST_ERR_BAD_PIDENT, row0 + list[e].pos); return; }
-    }
-    if (k == 1) {  // find_single_query_consensus.rs:74-150
-        const Entry h = list[0];
-        const uint32_t* row = t.lin + (uint64_t)h.tax * t.stride;
-        const uint32_t hdr = row[0], len = hdr & 0xFF, shape = hdr >> 8;
-        const double* cut = t.cut + (uint64_t)shape * t.sc;
-        uint64_t A = 0;
-        for (uint32_t j = 0; j < len; ++j) A |= (uint64_t)(h.pid >= cut[j]) << j;   // linnaean_ranks.rs:194-212
-        if (!A) { store_status(out, q, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, row0 + h.pos); return; }   // :113-119
-        const uint32_t last = (uint32_t)last_lane(A);
-        store_result(out, q, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, t.codes[(uint64_t)shape * t.sc + last] & 0xFFFF,
-                     BLU_NONE_U16, row[1 + last], row0 + h.pos, A, h.pid);
-        return;
-    }
-    // reference row, shortest lineage, group-max pident (find_multi_taxa_consensus.rs:39-68,142-145,182-185)
-    uint32_t r = 0, b_len = 0, b_acc = 0, b_hdr = 0, minlen = 0xFFFFFFFFu;
-    int b_aln = 0;
-    double b_pid = 0.0, max_pid = 0.0;
-    for (uint32_t e = 0; e < k; ++e) {
-        const Entry x = list[e];
-        const uint32_t hdr = t.lin[(uint64_t)x.tax * t.stride], len = hdr & 0xFF;
-        minlen = umin(minlen, len);
-        max_pid = x.pid > max_pid ? x.pid : max_pid;
-        const bool take = (e == 0) | key_better<STRAT>(len, x.pid, (int)x.aln, x.acc, b_len, b_pid, b_aln, b_acc);
-        r = take ? e : r;
-        b_len = take ? len : b_len;
-        b_pid = take ? x.pid : b_pid;
-        b_aln = take ? (int)x.aln : b_aln;
-        b_acc = take ? x.acc : b_acc;
-        b_hdr = take ? hdr : b_hdr;
-    }
-    const Entry R = list[r];
-    const uint32_t* ref = t.lin + (uint64_t)R.tax * t.stride;
-    // first level at which some row differs from the reference, scanning levels < minlen (:137-180)
-    uint32_t d = minlen;
-    for (uint32_t c = 0; c == 0 || 4 * c - 1 < d; ++c) {
-        const uint4 rw = *reinterpret_cast<const uint4*>(ref + 4 * c);
-        for (uint32_t e = 0; e < k; ++e) {
-            const uint4 w = *reinterpret_cast<const uint4*>(t.lin + (uint64_t)list[e].tax * t.stride + 4 * c);
-            const uint32_t base = 4 * c - 1;   // level of word .x (c == 0: header word, skipped)
-            if (c != 0 && base < d && w.x != rw.x) d = base;
-            if (base + 1 < d && w.y != rw.y) d = base + 1;
-            if (base + 2 < d && w.z != rw.z) d = base + 2;
-            if (base + 3 < d && w.w != rw.w) d = base + 3;
-        }
-    }
-    const bool agree = d >= minlen;
-    if (!agree && d == 0) { store_status(out, q, BLU_ST_ERR_ROOT_DISAGREE, row0 + R.pos); return; }   // :181
-    const uint32_t b = agree ? minlen - 1 : d - 1;
-    const double ident = agree ? R.pid : max_pid;
-    const uint32_t len_ref = b_hdr & 0xFF, shape = b_hdr >> 8;
-    const double* cut = t.cut + (uint64_t)shape * t.sc;
-    const uint32_t* codes = t.codes + (uint64_t)shape * t.sc;
-    // build_blast_consensus_identity.rs:9-105
-    uint64_t F = 0, A = 0;
-    uint32_t mar_level = BLU_NONE_U8, nF = 0;
-    for (uint32_t j = 0; j < len_ref; ++j) {
-        const double cj = cut[j];
-        if (mar_level == BLU_NONE_U8 && !(ident > cj)) mar_level = j;          // skip_while(identity > cutoff)
-        if (ident >= cj) {                                                    // filter(identity >= cutoff)
-            F |= 1ull << j;
-            if (nF <= b) A |= 1ull << j;                                      // first (b + 1) elements of the filtered list
-            ++nF;
-        }
-    }
-    if (agree) A = F;                                                         // single-flag branch (:74-75)
-    const uint32_t last = A ? (uint32_t)last_lane(A) : b;                     // .last().unwrap_or(taxonomy[bean_index])
-    uint32_t flags = agree ? BLU_FLAG_AGREE : 0u, mar_code = BLU_NONE_U16;
-    if (mar_level != BLU_NONE_U8) {
-        mar_code = codes[mar_level] >> 16;
-        if (mar_code != (codes[b] & 0xFFFF)) flags |= BLU_FLAG_MUTATED;       // bean.reached_rank != allowed_rank (:35-37)
-    }
-    store_result(out, q, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, codes[last] & 0xFFFF, mar_code, ref[1 + last],
-                 row0 + R.pos, A, ident);
-}
+struct WaveLds {
+    Entry list[LIST_CAP];       // top-group rows of the task's queries, file order
+    uint32_t hdr[LIST_CAP];     // lineage header (len | shape << 8) of list[i].tax, 0 = unmatched/bad
+    uint32_t meta[WAVE];        // first entry | k << 16 | META_SLOW
+    uint32_t ref_tax[WAVE];     // reference row's taxonomy row (NO_REF: nothing to compare)
+    uint32_t d[WAVE];           // min over the group of the first disagreeing level (starts at minlen)
+};
 
 template <int STRAT>
 __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                        uint32_t* __restrict__ worklist,
                                                                        uint32_t* __restrict__ work_count) {
-    __shared__ Entry s_list[WAVES_A][LIST_CAP];
-    __shared__ uint32_t s_meta[WAVES_A][WAVE];   // off | k << 16 | flags
-    __shared__ uint32_t s_row0[WAVES_A][WAVE];
+    __shared__ WaveLds s_lds[WAVES_A];
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-    Entry* list = s_list[wib];
-    uint32_t* meta = s_meta[wib];
-    uint32_t* row0s = s_row0[wib];
+    WaveLds& L = s_lds[wib];
     const uint64_t n_tasks = (h.n_queries + WAVE - 1) / WAVE;
     const uint64_t wave = (uint64_t)blockIdx.x * WAVES_A + wib;
     const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_A;
@@ -252,7 +170,7 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
     for (uint64_t task = wave; task < n_tasks; task += n_waves) {
         const uint64_t q0 = task * WAVE;
         const uint32_t nq = (uint32_t)((h.n_queries - q0) < WAVE ? (h.n_queries - q0) : WAVE);
-        // offsets of this task: lane i holds seg_off[q0 + i]; lane i + 1's value comes by DPP-free readlane below
+        // lane i holds the row range of query q0 + i
         uint64_t my_off = 0, my_end = 0;
         if ((uint32_t)lane < nq) {
             my_off = h.seg_off[q0 + lane];
@@ -262,21 +180,22 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
         }
         uint32_t fill = 0;   // wave-uniform: entries used in the LDS list
         // ---------------- phase 1: lane = hit ----------------
+        uint32_t g_hdr[BATCH], g_idx[BATCH];   // header gathers of the previous batch, written to LDS one batch later
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) { g_hdr[u] = 0; g_idx[u] = 0xFFFFFFFFu; }
         for (uint32_t qb = 0; qb < nq; qb += BATCH) {
             int bs[BATCH];
             uint32_t tax[BATCH], aln[BATCH], acc[BATCH], n[BATCH];
             double pid[BATCH];
-            uint64_t st[BATCH];
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const uint32_t qi = qb + u < nq ? qb + u : nq - 1;   // tail: re-read the last query, result discarded
-                st[u] = rl_u64(my_off, (int)qi);
-                const uint64_t en = rl_u64(my_end, (int)qi);
-                const uint64_t len = en - st[u];
+                const uint64_t st = rl_u64(my_off, (int)qi);
+                const uint64_t len = rl_u64(my_end, (int)qi) - st;
                 n[u] = len > WAVE ? WAVE + 1 : (uint32_t)len;
                 bs[u] = INT_MIN; tax[u] = 0; aln[u] = 0; acc[u] = 0; pid[u] = 0.0;
                 if ((uint32_t)lane < n[u] && n[u] <= WAVE) {
-                    const uint64_t row = st[u] + (uint32_t)lane;
+                    const uint64_t row = st + (uint32_t)lane;
                     bs[u] = h.bitscore[row];
                     tax[u] = h.tax_row[row];
                     pid[u] = h.pident[row];
@@ -284,42 +203,174 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                     acc[u] = h.acc_rank[row];
                 }
             }
+            // headers gathered during the previous batch have landed by now (they are older than this batch's loads)
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+                if (g_idx[u] != 0xFFFFFFFFu) L.hdr[g_idx[u]] = g_hdr[u];
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
-                if (qb + u >= nq) break;
-                uint32_t m;
-                if (n[u] == 0) m = META_EMPTY;
-                else if (n[u] > WAVE) m = META_SLOW;
-                else {
+                g_idx[u] = 0xFFFFFFFFu;
+                if (qb + u >= nq) continue;
+                uint32_t m = 0;
+                if (n[u] >= 1 && n[u] <= WAVE) {
                     const int M = wave_max_i32(bs[u]);
-                    const bool top = bs[u] == M;     // inactive lanes hold INT_MIN < M unless every score is INT_MIN
-                    const uint64_t mask = __ballot(top && (uint32_t)lane < n[u]);
+                    const uint64_t mask = __ballot(bs[u] == M && (uint32_t)lane < n[u]);
                     const uint32_t k = (uint32_t)__builtin_popcountll(mask);
                     if (fill + k > LIST_CAP) m = META_SLOW;
                     else {
                         if ((mask >> lane) & 1) {
                             const uint32_t idx = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                             Entry e;
-                            e.tax = tax[u]; e.aln = aln[u]; e.acc = acc[u]; e.pos = (uint32_t)lane; e.pid = pid[u];
-                            list[idx] = e;
+                            e.tax = tax[u]; e.aln = aln[u]; e.acc = acc[u]; e.pq = (uint32_t)lane | ((qb + u) << 8); e.pid = pid[u];
+                            L.list[idx] = e;
+                            g_idx[u] = idx;
+                            // first 4 bytes of the 64-byte lineage row; the later level compares hit the same line
+                            g_hdr[u] = tax[u] < t.n_tax ? t.lin[(uint64_t)tax[u] * t.stride] : 0u;
                         }
                         m = fill | (k << 16);
                         fill += k;
                     }
                 }
-                if (lane == 0) { meta[qb + u] = m; row0s[qb + u] = (uint32_t)st[u]; }
+                if (lane == 0) L.meta[qb + u] = m;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u)
+            if (g_idx[u] != 0xFFFFFFFFu) L.hdr[g_idx[u]] = g_hdr[u];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        // ---------------- phase 2a: lane = query, LDS only ----------------
+        // mode: 0 multi, 2 single, 3 finished (empty / error / handed to the worklist)
+        const uint64_t q = q0 + (uint32_t)lane;
+        const uint32_t row0 = (uint32_t)my_off;
+        uint32_t mode = 3, r_hdr = 0, r_tax = 0, r_pos = 0, minlen = 0;
+        double r_pid = 0.0, max_pid = 0.0;
+        L.ref_tax[lane] = NO_REF;
+        if ((uint32_t)lane < nq) {
+            const uint64_t nrows = my_end - my_off;
+            const uint32_t m = L.meta[lane];
+            if (nrows == 0) store_status(out, q, BLU_ST_NO_HITS, 0xFFFFFFFFu);            // mod.rs:107-113
+            else if (nrows > WAVE || (m & META_SLOW)) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
+            else {
+                const uint32_t first = m & 0xFFFF, k = (m >> 16) & 0xFF;
+                // parse errors first, in file order (find_single_query_consensus.rs:51-64), then NaN pident
+                uint32_t err = 0, err_pos = 0;
+                for (uint32_t e = 0; e < k; ++e) {
+                    const uint32_t hd = L.hdr[first + e];
+                    if (err == 0 && hd == 0) {
+                        err = L.list[first + e].tax >= t.n_tax ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE;
+                        err_pos = L.list[first + e].pq & 0xFF;
+                    }
+                }
+                if (err == 0)
+                    for (uint32_t e = 0; e < k; ++e) {
+                        const double p = L.list[first + e].pid;
+                        if (err == 0 && p != p) { err = BLU_ST_ERR_BAD_PIDENT; err_pos = L.list[first + e].pq & 0xFF; }
+                    }
+                if (err) store_status(out, q, err, row0 + err_pos);
+                else {
+                    // reference row, shortest lineage, group-max pident (find_multi_taxa_consensus.rs:39-68,142-145,182-185)
+                    uint32_t b_len = 0, b_acc = 0;
+                    int b_aln = 0;
+                    minlen = 0xFFFFFFFFu;
+                    for (uint32_t e = 0; e < k; ++e) {
+                        const Entry x = L.list[first + e];
+                        const uint32_t hd = L.hdr[first + e], len = hd & 0xFF;
+                        minlen = umin(minlen, len);
+                        max_pid = x.pid > max_pid ? x.pid : max_pid;
+                        const bool take = (e == 0) | key_better<STRAT>(len, x.pid, (int)x.aln, x.acc, b_len, r_pid, b_aln, b_acc);
+                        b_len = take ? len : b_len;
+                        r_pid = take ? x.pid : r_pid;
+                        b_aln = take ? (int)x.aln : b_aln;
+                        b_acc = take ? x.acc : b_acc;
+                        r_hdr = take ? hd : r_hdr;
+                        r_tax = take ? x.tax : r_tax;
+                        r_pos = take ? (x.pq & 0xFF) : r_pos;
+                    }
+                    mode = k == 1 ? 2u : 0u;
+                    if (k > 1) { L.ref_tax[lane] = r_tax; L.d[lane] = minlen; }
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // ---------------- phase 2: lane = query ----------------
-        if ((uint32_t)lane < nq) {
-            const uint32_t m = meta[lane];
-            const uint64_t q = q0 + (uint32_t)lane;
-            if (m & META_EMPTY) store_status(out, q, BLU_ST_NO_HITS, 0xFFFFFFFFu);
-            else if (m & META_SLOW) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
-            else finish_query<STRAT>(t, out, q, row0s[lane], list + (m & 0xFFFF), (m >> 16) & 0xFF);
+
+        // ---------------- phase 2b: lane = top-group row ----------------
+        // first level (< minlen) at which this row's lineage differs from its query's reference lineage (:137-180)
+        for (uint32_t base = 0; base < fill; base += WAVE) {
+            const uint32_t i = base + (uint32_t)lane;
+            if (i < fill) {
+                const uint32_t tax = L.list[i].tax, ql = L.list[i].pq >> 8;
+                const uint32_t rt = L.ref_tax[ql];
+                if (rt != NO_REF && rt != tax) {
+                    uint32_t d = L.d[ql];   // a smaller value written meanwhile only shortens the scan
+                    const uint32_t* own = t.lin + (uint64_t)tax * t.stride;
+                    const uint32_t* ref = t.lin + (uint64_t)rt * t.stride;
+                    bool hit = false;
+                    for (uint32_t c = 0; c == 0 || 4 * c - 1 < d; ++c) {
+                        const uint4 w = *reinterpret_cast<const uint4*>(own + 4 * c);
+                        const uint4 rw = *reinterpret_cast<const uint4*>(ref + 4 * c);
+                        const uint32_t lv = 4 * c - 1;   // level of word .x (c == 0: header word, skipped)
+                        if (c != 0 && lv < d && w.x != rw.x) { d = lv; hit = true; }
+                        if (lv + 1 < d && w.y != rw.y) { d = lv + 1; hit = true; }
+                        if (lv + 2 < d && w.z != rw.z) { d = lv + 2; hit = true; }
+                        if (lv + 3 < d && w.w != rw.w) { d = lv + 3; hit = true; }
+                    }
+                    if (hit) atomicMin(&L.d[ql], d);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        // ---------------- phase 2c: lane = query, cutoff tests and the record ----------------
+        if (mode != 3) {
+            const bool single = mode == 2;
+            const uint32_t d = single ? 0u : L.d[lane];
+            const bool agree = single | (d >= minlen);
+            if (!agree && d == 0) store_status(out, q, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
+            else {
+                const uint32_t len_ref = r_hdr & 0xFF, shape = r_hdr >> 8;
+                const uint32_t b = single ? len_ref : (agree ? minlen - 1 : d - 1);
+                const double ident = (single | agree) ? r_pid : max_pid;
+                const double* cut = t.cut + (uint64_t)shape * t.sc;
+                const uint32_t* codes = t.codes + (uint64_t)shape * t.sc;
+                // linnaean_ranks.rs:174-212 + build_blast_consensus_identity.rs:67-82
+                uint64_t F = 0, A = 0;
+                uint32_t mar_level = BLU_NONE_U8, nF = 0;
+                for (uint32_t j = 0; j < len_ref; ++j) {
+                    const double cj = cut[j];
+                    if (mar_level == BLU_NONE_U8 && !(ident > cj)) mar_level = j;   // skip_while(identity > cutoff)
+                    if (ident >= cj) {                                             // filter(identity >= cutoff)
+                        F |= 1ull << j;
+                        if (nF <= b) A |= 1ull << j;                               // first (b + 1) elements of the filtered list
+                        ++nF;
+                    }
+                }
+                if (agree) A = F;                                                  // single hit / single-flag branch (:74-75)
+                const uint32_t* ref = t.lin + (uint64_t)r_tax * t.stride;
+                if (single) {
+                    if (!A) store_status(out, q, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, row0 + r_pos);   // find_single_query_consensus.rs:113-119
+                    else {
+                        const uint32_t last = (uint32_t)last_lane(A);
+                        store_result(out, q, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, codes[last] & 0xFFFF, BLU_NONE_U16,
+                                     ref[1 + last], row0 + r_pos, A, ident);
+                    }
+                } else {
+                    const uint32_t last = A ? (uint32_t)last_lane(A) : b;          // .last().unwrap_or(taxonomy[bean_index])
+                    uint32_t flags = agree ? BLU_FLAG_AGREE : 0u, mar_code = BLU_NONE_U16;
+                    if (mar_level != BLU_NONE_U8) {
+                        mar_code = codes[mar_level] >> 16;
+                        if (mar_code != (codes[b] & 0xFFFF)) flags |= BLU_FLAG_MUTATED;   // bean.reached_rank != allowed_rank (:35-37)
+                    }
+                    store_result(out, q, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, codes[last] & 0xFFFF, mar_code,
+                                 ref[1 + last], row0 + r_pos, A, ident);
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
