@@ -1,6 +1,8 @@
 // Internal declarations shared by the host side and the HIP kernels of
 // libblu_consensus.so.  Not part of the ABI (include/blu_consensus.h is).
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include <cstdint>
 #include <string>
 #include <unordered_map>
@@ -22,7 +24,17 @@ struct RankInfo {
 
 // Device view of the taxonomy (passed to kernels by value).
 struct TaxDev {
-    const uint32_t* lin;    // [n_tax][stride] word0 = len | shape << 8 (len 0 = bad lineage), words 1.. = node ids
+    // Lineage rows in LEXICOGRAPHIC order of their node sequences (row index = "pos"):
+    // word0 = len | shape << 8 (len 0 = bad lineage), words 1.. = node ids, root -> leaf.
+    const uint32_t* lin;    // [n_tax][stride]
+    // caller's tax_row -> {header word, pos}; 8 bytes per taxid, the only table the streaming phase touches
+    const uint2* info;      // [n_tax]
+    // lcp8[i] = number of leading levels shared by sorted rows i and i+1.  In that order the levels shared by a
+    // whole group of rows = min(lcp8[lo .. hi-1]) for the group's smallest/largest pos: a range-minimum query
+    // replaces the per-row level scan of find_multi_taxa_consensus.rs:137-180.
+    const uint8_t* lcp8;    // [n_tax - 1], padded with 0xFF to a multiple of 16 (+16)
+    const uint8_t* rmq;     // sparse table over 16-entry blocks of lcp8: level k at rmq + k * rmq_nb, entry j = min of blocks j .. j+2^k-1
+    uint32_t rmq_nb;        // blocks per level
     const double* cut;      // [n_shapes][sc] per-level identity cutoff
     const uint32_t* codes;  // [n_shapes][sc] rank_code | mar_code << 16
     uint64_t n_tax;
@@ -68,6 +80,11 @@ struct blu_taxonomy {
     uint32_t n_shapes = 0;
     std::unordered_map<int64_t, uint32_t> taxid_row;
     uint32_t* d_lin = nullptr;
+    uint2* d_info = nullptr;
+    uint8_t* d_lcp8 = nullptr;
+    uint8_t* d_rmq = nullptr;
+    uint32_t rmq_nb = 0;
+    std::vector<uint32_t> pos_of;            // caller's tax_row -> sorted position
     double* d_cut = nullptr;
     uint32_t* d_codes = nullptr;
     uint64_t device_bytes = 0;

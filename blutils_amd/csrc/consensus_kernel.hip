@@ -135,24 +135,68 @@ __device__ __forceinline__ bool key_better(uint32_t len, double pid, int aln, ui
     return !(gt | eq);
 }
 
+// ---- shared levels of a group of rows: range minimum over the adjacent-row LCP array -------------------
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+// OR-mask that forces the bytes of one 32-bit word outside [s, e) (byte indices relative to the word) to 0xFF
+__device__ __forceinline__ uint32_t exclude_mask(int s, int e) {
+    const int a = s < 0 ? 0 : (s > 4 ? 4 : s);
+    const int b = e < 0 ? 0 : (e > 4 ? 4 : e);
+    const uint64_t low = (1ull << (8 * a)) - 1ull;
+    const uint64_t high = ~((1ull << (8 * b)) - 1ull);
+    return (uint32_t)(low | high);
+}
+// min of bytes [s, e) of the 16-byte block `blk` of lcp8 (0 <= s < e <= 16)
+__device__ __forceinline__ uint32_t block_min(const TaxDev& t, uint32_t blk, int s, int e) {
+    const uint4 w = *reinterpret_cast<const uint4*>(t.lcp8 + (uint64_t)blk * 16);
+    const uint32_t x[4] = {w.x | exclude_mask(s, e), w.y | exclude_mask(s - 4, e - 4), w.z | exclude_mask(s - 8, e - 8),
+                           w.w | exclude_mask(s - 12, e - 12)};
+    us2 acc = {0xFF, 0xFF};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t a = x[i] & 0x00FF00FFu, b = (x[i] >> 8) & 0x00FF00FFu;
+        acc = __builtin_elementwise_min(acc, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+    }
+    return acc.x < acc.y ? acc.x : acc.y;
+}
+// min(lcp8[lo .. hi-1]) for lo < hi: number of leading levels shared by every row with lo <= pos <= hi
+__device__ __forceinline__ uint32_t shared_levels(const TaxDev& t, uint32_t lo, uint32_t hi) {
+    const uint32_t b0 = (lo + 15) >> 4, b1 = hi >> 4;
+    if (b0 > b1) return block_min(t, lo >> 4, (int)(lo & 15), (int)(hi - ((lo >> 4) << 4)));
+    uint32_t m = 0xFF;
+    if (lo & 15) m = umin(m, block_min(t, lo >> 4, (int)(lo & 15), 16));
+    if (hi & 15) m = umin(m, block_min(t, b1, 0, (int)(hi & 15)));
+    if (b0 < b1) {
+        const uint32_t k = 31 - __builtin_clz(b1 - b0);
+        const uint8_t* lvl = t.rmq + (uint64_t)k * t.rmq_nb;
+        m = umin(m, umin(lvl[b0], lvl[b1 - (1u << k)]));
+    }
+    return m;
+}
+
 // ===============================================================================
 // Kernel A
 // ===============================================================================
 struct Entry {            // one top-group row in LDS, 24 bytes
-    uint32_t tax, aln, acc, pq;   // pq = position in the segment | query-in-task << 8
+    uint32_t pos, aln, acc, pq;   // pos = sorted position of the row's lineage; pq = position in the segment | query-in-task << 8
     double pid;
 };
 static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 
 #define META_SLOW 0x80000000u
-#define NO_REF 0xFFFFFFFFu
+// the five hit columns are read exactly once per run: non-temporal loads keep them from displacing the
+// lineage rows and cutoff tables (re-read by every query) in L2 / Infinity Cache
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#ifdef BLU_EXP_NO_NT
+#define STREAM_AUX 0
+#else
+#define STREAM_AUX 2   // nt
+#endif
 
 struct WaveLds {
     Entry list[LIST_CAP];       // top-group rows of the task's queries, file order
-    uint32_t hdr[LIST_CAP];     // lineage header (len | shape << 8) of list[i].tax, 0 = unmatched/bad
+    uint32_t hdr[LIST_CAP];     // lineage header (len | shape << 8); 0 = unmatched taxid (pos 0xFFFFFFFF) or bad lineage
     uint32_t meta[WAVE];        // first entry | k << 16 | META_SLOW
-    uint32_t ref_tax[WAVE];     // reference row's taxonomy row (NO_REF: nothing to compare)
-    uint32_t d[WAVE];           // min over the group of the first disagreeing level (starts at minlen)
 };
 
 template <int STRAT>
@@ -179,10 +223,24 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
             if (my_off > my_end) my_off = my_end;
         }
         uint32_t fill = 0;   // wave-uniform: entries used in the LDS list
+        // Row offsets relative to the task's first row fit 32 bits (n_hits < 2^32).  One buffer descriptor per
+        // column, based at the task's first row: 32-bit lane offsets, no 64-bit VALU address math, and the
+        // hardware range check returns 0 for lanes that run past the end of the table.
+        const uint64_t task_start = rl_u64(my_off, 0);
+        const uint32_t rel_off = (uint32_t)(my_off - task_start), rel_end = (uint32_t)(my_end - task_start);
+        const uint64_t rem = h.n_hits - task_start;
+        const uint32_t rem4 = (uint32_t)(rem * 4 > 0xFFFFFFFFull ? 0xFFFFFFFFull : rem * 4);
+        const uint32_t rem8 = (uint32_t)(rem * 8 > 0xFFFFFFFFull ? 0xFFFFFFFFull : rem * 8);
+        const auto rs_bs = __builtin_amdgcn_make_buffer_rsrc((void*)(h.bitscore + task_start), 0, rem4, 0x00020000);
+        const auto rs_tax = __builtin_amdgcn_make_buffer_rsrc((void*)(h.tax_row + task_start), 0, rem4, 0x00020000);
+        const auto rs_aln = __builtin_amdgcn_make_buffer_rsrc((void*)(h.align_len + task_start), 0, rem4, 0x00020000);
+        const auto rs_acc = __builtin_amdgcn_make_buffer_rsrc((void*)(h.acc_rank + task_start), 0, rem4, 0x00020000);
+        const auto rs_pid = __builtin_amdgcn_make_buffer_rsrc((void*)(h.pident + task_start), 0, rem8, 0x00020000);
         // ---------------- phase 1: lane = hit ----------------
-        uint32_t g_hdr[BATCH], g_idx[BATCH];   // header gathers of the previous batch, written to LDS one batch later
+        uint2 g_inf[BATCH];                    // {header, pos} gathers of the previous batch, written to LDS one batch later
+        uint32_t g_idx[BATCH];
 #pragma unroll
-        for (int u = 0; u < BATCH; ++u) { g_hdr[u] = 0; g_idx[u] = 0xFFFFFFFFu; }
+        for (int u = 0; u < BATCH; ++u) { g_inf[u] = make_uint2(0u, 0xFFFFFFFFu); g_idx[u] = 0xFFFFFFFFu; }
         for (uint32_t qb = 0; qb < nq; qb += BATCH) {
             int bs[BATCH];
             uint32_t tax[BATCH], aln[BATCH], acc[BATCH], n[BATCH];
@@ -190,42 +248,50 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const uint32_t qi = qb + u < nq ? qb + u : nq - 1;   // tail: re-read the last query, result discarded
-                const uint64_t st = rl_u64(my_off, (int)qi);
-                const uint64_t len = rl_u64(my_end, (int)qi) - st;
-                n[u] = len > WAVE ? WAVE + 1 : (uint32_t)len;
-                bs[u] = INT_MIN; tax[u] = 0; aln[u] = 0; acc[u] = 0; pid[u] = 0.0;
-                if ((uint32_t)lane < n[u] && n[u] <= WAVE) {
-                    const uint64_t row = st + (uint32_t)lane;
-                    bs[u] = h.bitscore[row];
-                    tax[u] = h.tax_row[row];
-                    pid[u] = h.pident[row];
-                    aln[u] = (uint32_t)h.align_len[row];
-                    acc[u] = h.acc_rank[row];
-                }
+                const uint32_t so = (uint32_t)rl((int)rel_off, (int)qi);
+                n[u] = (uint32_t)rl((int)rel_end, (int)qi) - so;
+                // unconditional loads (lanes past the segment read the next query's rows or get 0 past the table):
+                // no VALU write touches a register with a load in flight, so no wait is needed before issuing
+                const uint32_t voff = (so + (uint32_t)lane) * 4u;
+                bs[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_bs, voff, 0, STREAM_AUX);
+                tax[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_tax, voff, 0, STREAM_AUX);
+                const u32x2 pw = __builtin_amdgcn_raw_buffer_load_b64(rs_pid, voff * 2u, 0, STREAM_AUX);
+                pid[u] = __hiloint2double((int)pw.y, (int)pw.x);
+                aln[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_aln, voff, 0, STREAM_AUX);
+                acc[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_acc, voff, 0, STREAM_AUX);
             }
             // headers gathered during the previous batch have landed by now (they are older than this batch's loads)
 #pragma unroll
             for (int u = 0; u < BATCH; ++u)
-                if (g_idx[u] != 0xFFFFFFFFu) L.hdr[g_idx[u]] = g_hdr[u];
+                if (g_idx[u] != 0xFFFFFFFFu) { L.hdr[g_idx[u]] = g_inf[u].x; L.list[g_idx[u]].pos = g_inf[u].y; }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 g_idx[u] = 0xFFFFFFFFu;
+                // Every loaded register is read here on every path, so that no load of this batch is still
+                // "possibly in flight" at the loop back-edge (the compiler would otherwise park a vmcnt(0)
+                // at the loop head, in front of the next batch's loads and behind this batch's header gathers).
+                asm volatile("" ::"v"(bs[u]), "v"(tax[u]), "v"(aln[u]), "v"(acc[u]), "v"(pid[u]));
                 if (qb + u >= nq) continue;
                 uint32_t m = 0;
                 if (n[u] >= 1 && n[u] <= WAVE) {
-                    const int M = wave_max_i32(bs[u]);
-                    const uint64_t mask = __ballot(bs[u] == M && (uint32_t)lane < n[u]);
+                    const bool act = (uint32_t)lane < n[u];
+                    const int M = wave_max_i32(act ? bs[u] : INT_MIN);
+                    const uint64_t mask = __ballot(act && bs[u] == M);
                     const uint32_t k = (uint32_t)__builtin_popcountll(mask);
                     if (fill + k > LIST_CAP) m = META_SLOW;
                     else {
                         if ((mask >> lane) & 1) {
                             const uint32_t idx = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                             Entry e;
-                            e.tax = tax[u]; e.aln = aln[u]; e.acc = acc[u]; e.pq = (uint32_t)lane | ((qb + u) << 8); e.pid = pid[u];
+                            e.pos = 0xFFFFFFFFu; e.aln = aln[u]; e.acc = acc[u]; e.pq = (uint32_t)lane | ((qb + u) << 8); e.pid = pid[u];
                             L.list[idx] = e;
                             g_idx[u] = idx;
-                            // first 4 bytes of the 64-byte lineage row; the later level compares hit the same line
-                            g_hdr[u] = tax[u] < t.n_tax ? t.lin[(uint64_t)tax[u] * t.stride] : 0u;
+                            // 8 bytes per taxid {header, sorted position}: the only taxonomy data phase 1 touches
+#ifdef BLU_EXP_P1ONLY
+                            g_inf[u] = make_uint2(tax[u], tax[u]);
+#else
+                            g_inf[u] = tax[u] < t.n_tax ? t.info[tax[u]] : make_uint2(0u, 0xFFFFFFFFu);
+#endif
                         }
                         m = fill | (k << 16);
                         fill += k;
@@ -236,18 +302,21 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
         }
 #pragma unroll
         for (int u = 0; u < BATCH; ++u)
-            if (g_idx[u] != 0xFFFFFFFFu) L.hdr[g_idx[u]] = g_hdr[u];
+            if (g_idx[u] != 0xFFFFFFFFu) { L.hdr[g_idx[u]] = g_inf[u].x; L.list[g_idx[u]].pos = g_inf[u].y; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
+#ifdef BLU_EXP_P1ONLY
+        if ((uint32_t)lane < nq) store_status(out, q0 + (uint32_t)lane, 2, L.hdr[L.meta[lane] & 0xFF] + (uint32_t)L.list[L.meta[lane] & 0xFF].pid + L.list[L.meta[lane] & 0xFF].pos);
+        continue;
+#endif
         // ---------------- phase 2a: lane = query, LDS only ----------------
         // mode: 0 multi, 2 single, 3 finished (empty / error / handed to the worklist)
         const uint64_t q = q0 + (uint32_t)lane;
         const uint32_t row0 = (uint32_t)my_off;
-        uint32_t mode = 3, r_hdr = 0, r_tax = 0, r_pos = 0, minlen = 0;
+        uint32_t mode = 3, r_hdr = 0, r_row = 0, r_pos = 0, minlen = 0, d = 0;
         double r_pid = 0.0, max_pid = 0.0;
-        L.ref_tax[lane] = NO_REF;
         if ((uint32_t)lane < nq) {
             const uint64_t nrows = my_end - my_off;
             const uint32_t m = L.meta[lane];
@@ -260,7 +329,7 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                 for (uint32_t e = 0; e < k; ++e) {
                     const uint32_t hd = L.hdr[first + e];
                     if (err == 0 && hd == 0) {
-                        err = L.list[first + e].tax >= t.n_tax ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE;
+                        err = L.list[first + e].pos == 0xFFFFFFFFu ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE;
                         err_pos = L.list[first + e].pq & 0xFF;
                     }
                 }
@@ -272,13 +341,16 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                 if (err) store_status(out, q, err, row0 + err_pos);
                 else {
                     // reference row, shortest lineage, group-max pident (find_multi_taxa_consensus.rs:39-68,142-145,182-185)
-                    uint32_t b_len = 0, b_acc = 0;
+                    // and the span [lo, hi] of the group in the sorted lineage order
+                    uint32_t b_len = 0, b_acc = 0, lo = 0xFFFFFFFFu, hi = 0;
                     int b_aln = 0;
                     minlen = 0xFFFFFFFFu;
                     for (uint32_t e = 0; e < k; ++e) {
                         const Entry x = L.list[first + e];
                         const uint32_t hd = L.hdr[first + e], len = hd & 0xFF;
                         minlen = umin(minlen, len);
+                        lo = umin(lo, x.pos);
+                        hi = x.pos > hi ? x.pos : hi;
                         max_pid = x.pid > max_pid ? x.pid : max_pid;
                         const bool take = (e == 0) | key_better<STRAT>(len, x.pid, (int)x.aln, x.acc, b_len, r_pid, b_aln, b_acc);
                         b_len = take ? len : b_len;
@@ -286,51 +358,26 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                         b_aln = take ? (int)x.aln : b_aln;
                         b_acc = take ? x.acc : b_acc;
                         r_hdr = take ? hd : r_hdr;
-                        r_tax = take ? x.tax : r_tax;
+                        r_row = take ? x.pos : r_row;
                         r_pos = take ? (x.pq & 0xFF) : r_pos;
                     }
                     mode = k == 1 ? 2u : 0u;
-                    if (k > 1) { L.ref_tax[lane] = r_tax; L.d[lane] = minlen; }
+                    // levels shared by the whole group (:137-180): every row agrees with the reference row on exactly
+                    // the levels all rows share, and the scan never looks past the shortest lineage
+                    d = minlen;
+                    if (k > 1 && lo < hi) d = umin(minlen, shared_levels(t, lo, hi));
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-        // ---------------- phase 2b: lane = top-group row ----------------
-        // first level (< minlen) at which this row's lineage differs from its query's reference lineage (:137-180)
-        for (uint32_t base = 0; base < fill; base += WAVE) {
-            const uint32_t i = base + (uint32_t)lane;
-            if (i < fill) {
-                const uint32_t tax = L.list[i].tax, ql = L.list[i].pq >> 8;
-                const uint32_t rt = L.ref_tax[ql];
-                if (rt != NO_REF && rt != tax) {
-                    uint32_t d = L.d[ql];   // a smaller value written meanwhile only shortens the scan
-                    const uint32_t* own = t.lin + (uint64_t)tax * t.stride;
-                    const uint32_t* ref = t.lin + (uint64_t)rt * t.stride;
-                    bool hit = false;
-                    for (uint32_t c = 0; c == 0 || 4 * c - 1 < d; ++c) {
-                        const uint4 w = *reinterpret_cast<const uint4*>(own + 4 * c);
-                        const uint4 rw = *reinterpret_cast<const uint4*>(ref + 4 * c);
-                        const uint32_t lv = 4 * c - 1;   // level of word .x (c == 0: header word, skipped)
-                        if (c != 0 && lv < d && w.x != rw.x) { d = lv; hit = true; }
-                        if (lv + 1 < d && w.y != rw.y) { d = lv + 1; hit = true; }
-                        if (lv + 2 < d && w.z != rw.z) { d = lv + 2; hit = true; }
-                        if (lv + 3 < d && w.w != rw.w) { d = lv + 3; hit = true; }
-                    }
-                    if (hit) atomicMin(&L.d[ql], d);
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
         // ---------------- phase 2c: lane = query, cutoff tests and the record ----------------
+#ifdef BLU_EXP_SKIP_2C
+        if (mode != 3) store_status(out, q, mode, r_row + minlen + d + r_pos + r_hdr);
+        if (false) {
+#else
         if (mode != 3) {
+#endif
             const bool single = mode == 2;
-            const uint32_t d = single ? 0u : L.d[lane];
             const bool agree = single | (d >= minlen);
             if (!agree && d == 0) store_status(out, q, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
             else {
@@ -342,17 +389,26 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                 // linnaean_ranks.rs:174-212 + build_blast_consensus_identity.rs:67-82
                 uint64_t F = 0, A = 0;
                 uint32_t mar_level = BLU_NONE_U8, nF = 0;
-                for (uint32_t j = 0; j < len_ref; ++j) {
-                    const double cj = cut[j];
-                    if (mar_level == BLU_NONE_U8 && !(ident > cj)) mar_level = j;   // skip_while(identity > cutoff)
-                    if (ident >= cj) {                                             // filter(identity >= cutoff)
-                        F |= 1ull << j;
-                        if (nF <= b) A |= 1ull << j;                               // first (b + 1) elements of the filtered list
-                        ++nF;
+                for (uint32_t j0 = 0; j0 < len_ref; j0 += 8) {   // cutoff rows are padded to a multiple of 16 entries
+                    double2 cc[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) cc[v] = *reinterpret_cast<const double2*>(cut + j0 + 2 * v);
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        const uint32_t j = j0 + v;
+                        const double cj = (v & 1) ? cc[v >> 1].y : cc[v >> 1].x;
+                        if (j < len_ref) {
+                            if (mar_level == BLU_NONE_U8 && !(ident > cj)) mar_level = j;   // skip_while(identity > cutoff)
+                            if (ident >= cj) {                                             // filter(identity >= cutoff)
+                                F |= 1ull << j;
+                                if (nF <= b) A |= 1ull << j;                               // first (b + 1) elements of the filtered list
+                                ++nF;
+                            }
+                        }
                     }
                 }
                 if (agree) A = F;                                                  // single hit / single-flag branch (:74-75)
-                const uint32_t* ref = t.lin + (uint64_t)r_tax * t.stride;
+                const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
                 if (single) {
                     if (!A) store_status(out, q, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, row0 + r_pos);   // find_single_query_consensus.rs:113-119
                     else {
@@ -411,27 +467,6 @@ __device__ __forceinline__ int select_reference(bool valid, uint32_t len, uint32
     return first_lane(cand);
 }
 
-// First level (< bound) at which some valid lane's lineage differs from the reference
-// lineage (lane j of ref_node = node of level j); `bound` when none does.
-__device__ __forceinline__ uint32_t first_disagreement(const TaxDev& t, bool valid, uint32_t tax, uint32_t ref_node,
-                                                       uint32_t bound) {
-    const uint32_t* row = t.lin + (uint64_t)(valid ? tax : 0u) * t.stride;
-    for (uint32_t c = 0; c == 0 || 4 * c - 1 < bound; ++c) {
-        uint4 w = {0, 0, 0, 0};
-        if (valid) w = *reinterpret_cast<const uint4*>(row + 4 * c);
-        const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (c == 0 && k == 0) continue;  // header word
-            const uint32_t lvl = 4 * c + k - 1;
-            if (lvl >= bound) return bound;
-            const uint32_t rn = (uint32_t)rl((int)ref_node, (int)lvl);
-            if (__ballot(valid && wv[k] != rn)) return lvl;
-        }
-    }
-    return bound;
-}
-
 template <int STRAT>
 __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                  const uint32_t* __restrict__ worklist,
@@ -458,7 +493,8 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
         const int M = wave_max_i32(m);
         // pass 2: group size, errors in file order, lane-local best key / shortest lineage / max pident
         uint32_t k = 0, err_status = 0, err_row = 0;
-        uint32_t have = 0, b_len = 0, b_acc = 0, b_pos = 0, b_tax = 0, b_shape = 0, l_minlen = 0xFFFFFFFFu;
+        uint32_t have = 0, b_len = 0, b_acc = 0, b_pos = 0, b_row = 0, b_shape = 0, l_minlen = 0xFFFFFFFFu;
+        uint32_t l_lo = 0xFFFFFFFFu, l_hi = 0;   // span of this lane's top rows in the sorted lineage order
         int b_aln = 0;
         double b_pid = 0.0, l_maxpid = 0.0;
         for (uint32_t base = 0; base < n && err_status == 0; base += WAVE) {
@@ -474,8 +510,8 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             const int aln = c_aln[ii];
             const uint32_t acc = c_acc[ii];
             const bool unmatched = top && tax >= t.n_tax;
-            const uint32_t hdr = t.lin[(uint64_t)((top && !unmatched) ? tax : 0u) * t.stride];
-            const uint32_t len = hdr & 0xFF;
+            const uint2 inf = t.info[(top && !unmatched) ? tax : 0u];   // {header, sorted position}
+            const uint32_t hdr = inf.x, len = hdr & 0xFF;
             const bool bad = top && !unmatched && len == 0;
             const uint64_t um = __ballot(unmatched), bm = __ballot(bad);
             if (um | bm) {   // parse_taxonomy Err at the first failing row (find_single_query_consensus.rs:58-60)
@@ -491,9 +527,11 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             b_aln = take ? aln : b_aln;
             b_acc = take ? acc : b_acc;
             b_pos = take ? i : b_pos;
-            b_tax = take ? tax : b_tax;
+            b_row = take ? inf.y : b_row;
             b_shape = take ? (hdr >> 8) : b_shape;
             l_minlen = top ? umin(l_minlen, len) : l_minlen;
+            l_lo = top ? umin(l_lo, inf.y) : l_lo;
+            l_hi = (top && inf.y > l_hi) ? inf.y : l_hi;
             l_maxpid = (top && pid > l_maxpid) ? pid : l_maxpid;
         }
         if (err_status) {
@@ -525,14 +563,14 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             const uint32_t len_ext = STRAT == BLU_RELAXED ? wave_max_u32(have ? b_len : 0u) : wave_min_u32(have ? b_len : 0xFFFFFFFFu);
             rlane = select_reference<STRAT>(have != 0, b_len, len_ext, b_pid, b_aln, b_acc, b_pos);
         }
-        const uint32_t tax_ref = (uint32_t)rl((int)b_tax, rlane);
+        const uint32_t row_ref = (uint32_t)rl((int)b_row, rlane);
         const uint32_t len_ref = (uint32_t)rl((int)b_len, rlane);
         const uint32_t shape_ref = (uint32_t)rl((int)b_shape, rlane);
         const uint32_t pos_ref = (uint32_t)rl((int)b_pos, rlane);
         const double pid_ref = rl_f64(b_pid, rlane);
         const bool in_l = (uint32_t)lane < len_ref;
         const uint32_t lvl = in_l ? (uint32_t)lane : 0u;
-        const uint32_t ref_node = t.lin[(uint64_t)tax_ref * t.stride + 1 + lvl];
+        const uint32_t ref_node = t.lin[(uint64_t)row_ref * t.stride + 1 + lvl];
         const double cut = t.cut[(uint64_t)shape_ref * t.sc + lvl];
         const uint32_t codes = t.codes[(uint64_t)shape_ref * t.sc + lvl];
         const uint32_t ref_row = (uint32_t)start + pos_ref;
@@ -546,15 +584,10 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             continue;
         }
         const uint32_t minlen = wave_min_u32(l_minlen);
-        // pass 3: first disagreeing level over every top row; the bound shrinks as mismatches are found
+        // levels shared by the whole top group = range minimum of the adjacent-row LCP array over its span (:137-180)
+        const uint32_t lo = wave_min_u32(l_lo), hi = wave_max_u32(l_hi);
         uint32_t d = minlen;
-        for (uint32_t base = 0; base < n && d > 0; base += WAVE) {
-            const uint32_t i = base + (uint32_t)lane;
-            const bool top = i < n && c_bs[i < n ? i : 0] == M;
-            if (!__ballot(top)) continue;
-            const uint32_t tax = c_tax[top ? i : 0];
-            d = first_disagreement(t, top, tax, ref_node, d);
-        }
+        if (lo < hi) d = umin(minlen, shared_levels(t, lo, hi));
         const bool agree = d >= minlen;
         if (!agree && d == 0) { if (lane == 0) store_status(out, q, BLU_ST_ERR_ROOT_DISAGREE, ref_row); continue; }
         const uint32_t b = agree ? minlen - 1 : d - 1;

@@ -263,6 +263,52 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         for (uint64_t t = 0; t < desc->n_tax; ++t) tax->taxid_row.emplace(desc->taxid[t], (uint32_t)t);
     }
 
+    // ---- lexicographic order of the lineage rows, adjacent-row LCP, block sparse table -------------------
+    const uint64_t n = desc->n_tax;
+    std::vector<uint32_t> order(n);
+    for (uint64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    const uint32_t stride = tax->stride;
+    const uint32_t* L = tax->h_lin.data();
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        const uint32_t* ra = L + (size_t)a * stride;
+        const uint32_t* rb = L + (size_t)b * stride;
+        const uint32_t la = ra[0] & 0xFF, lb = rb[0] & 0xFF, m = la < lb ? la : lb;
+        for (uint32_t j = 1; j <= m; ++j)
+            if (ra[j] != rb[j]) return ra[j] < rb[j];
+        if (la != lb) return la < lb;
+        return a < b;
+    });
+    tax->pos_of.assign(n, 0);
+    for (uint64_t i = 0; i < n; ++i) tax->pos_of[order[i]] = (uint32_t)i;
+    std::vector<uint32_t> lin_sorted((size_t)n * stride);
+    for (uint64_t i = 0; i < n; ++i)
+        memcpy(&lin_sorted[(size_t)i * stride], L + (size_t)order[i] * stride, stride * sizeof(uint32_t));
+    std::vector<uint2> info(std::max<uint64_t>(n, 1));
+    for (uint64_t t = 0; t < n; ++t) info[t] = make_uint2(L[(size_t)t * stride], tax->pos_of[t]);
+    const uint64_t n_lcp = n > 0 ? n - 1 : 0;
+    const uint32_t nb = (uint32_t)((n_lcp + 15) / 16) + 1;            // 16-entry blocks (+1 block of padding)
+    std::vector<uint8_t> lcp8((size_t)nb * 16 + 16, 0xFF);
+    for (uint64_t i = 0; i < n_lcp; ++i) {
+        const uint32_t* ra = &lin_sorted[(size_t)i * stride];
+        const uint32_t* rb = ra + stride;
+        const uint32_t la = ra[0] & 0xFF, lb = rb[0] & 0xFF, m = la < lb ? la : lb;
+        uint32_t c = 0;
+        while (c < m && ra[1 + c] == rb[1 + c]) ++c;
+        lcp8[i] = (uint8_t)c;
+    }
+    uint32_t levels = 1;
+    while ((1u << levels) <= nb) ++levels;
+    std::vector<uint8_t> rmq((size_t)levels * nb, 0xFF);
+    for (uint32_t j = 0; j < nb; ++j) {
+        uint8_t m = 0xFF;
+        for (int b = 0; b < 16; ++b) m = std::min(m, lcp8[(size_t)j * 16 + b]);
+        rmq[j] = m;
+    }
+    for (uint32_t k = 1; k < levels; ++k)
+        for (uint32_t j = 0; j + (1u << k) <= nb; ++j)
+            rmq[(size_t)k * nb + j] = std::min(rmq[(size_t)(k - 1) * nb + j], rmq[(size_t)(k - 1) * nb + j + (1u << (k - 1))]);
+    tax->rmq_nb = nb;
+
     if (device >= 0) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -273,13 +319,20 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         hipDeviceProp_t prop;
         if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
         if (e == hipSuccess) tax->num_cus = prop.multiProcessorCount;
-        size_t b_lin = std::max<size_t>(tax->h_lin.size(), 16) * sizeof(uint32_t);
+        size_t b_lin = std::max<size_t>(lin_sorted.size(), 16) * sizeof(uint32_t);
+        size_t b_info = info.size() * sizeof(uint2);
         size_t b_cut = tax->h_cut.size() * sizeof(double);
         size_t b_codes = tax->h_codes.size() * sizeof(uint32_t);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lin, b_lin);
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_info, b_info);
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lcp8, lcp8.size());
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_rmq, rmq.size());
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_cut, b_cut);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_codes, b_codes);
-        if (e == hipSuccess && !tax->h_lin.empty()) e = hipMemcpy(tax->d_lin, tax->h_lin.data(), tax->h_lin.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !lin_sorted.empty()) e = hipMemcpy(tax->d_lin, lin_sorted.data(), lin_sorted.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(tax->d_info, info.data(), b_info, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(tax->d_lcp8, lcp8.data(), lcp8.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(tax->d_rmq, rmq.data(), rmq.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_cut, tax->h_cut.data(), b_cut, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_codes, tax->h_codes.data(), b_codes, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -287,7 +340,7 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
             blu_taxonomy_destroy(tax);
             return BLU_ERR_HIP;
         }
-        tax->device_bytes = b_lin + b_cut + b_codes;
+        tax->device_bytes = b_lin + b_info + lcp8.size() + rmq.size() + b_cut + b_codes;
     }
     *out = tax;
     return BLU_OK;
@@ -298,6 +351,9 @@ void blu_taxonomy_destroy(blu_taxonomy* tax) {
     if (tax->device >= 0) {
         (void)hipSetDevice(tax->device);
         if (tax->d_lin) (void)hipFree(tax->d_lin);
+        if (tax->d_info) (void)hipFree(tax->d_info);
+        if (tax->d_lcp8) (void)hipFree(tax->d_lcp8);
+        if (tax->d_rmq) (void)hipFree(tax->d_rmq);
         if (tax->d_cut) (void)hipFree(tax->d_cut);
         if (tax->d_codes) (void)hipFree(tax->d_codes);
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);

@@ -1,0 +1,13 @@
+#!/bin/bash
+# usage: scripts/pmc.sh <outdir> "<counters pass 1>" "<counters pass 2>" ...
+# one rocprofv3 --pmc run per counter group (gfx950: FETCH_SIZE and WRITE_SIZE do not fit one pass)
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=$1; shift; mkdir -p $out
+i=0
+for grp in "$@"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --kernel-include-regex "blu_" --output-format csv -d $out/pass$i -- \
+     python3 bench.py --steps 3 --warmup 1 --no-parity-gate --no-cpu-baseline $PMC_BENCH_ARGS > $out/pass$i.json 2> $out/pass$i.log
+  echo "pass $i ($grp) rc=$?"
+done
+python3 scripts/pmc_summary.py $out
