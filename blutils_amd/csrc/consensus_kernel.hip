@@ -119,6 +119,21 @@ __device__ __forceinline__ void store_result(blu_result* out, uint64_t q, uint32
     p[0] = a;
     p[1] = b;
 }
+__device__ __forceinline__ void pack_result(uint4& a, uint4& b, uint32_t status, uint32_t flags, uint32_t bean_index,
+                                            uint32_t mar_level, uint32_t reached_rank, uint32_t mar_code, uint32_t identifier,
+                                            uint32_t ref_row, uint64_t level_mask, double ident) {
+    a.x = (status & 0xFF) | ((flags & 0xFF) << 8) | ((bean_index & 0xFF) << 16) | ((mar_level & 0xFF) << 24);
+    a.y = (reached_rank & 0xFFFF) | ((mar_code & 0xFFFF) << 16);
+    a.z = identifier;
+    a.w = ref_row;
+    b.x = (uint32_t)level_mask;
+    b.y = (uint32_t)(level_mask >> 32);
+    b.z = (uint32_t)__double2loint(ident);
+    b.w = (uint32_t)__double2hiint(ident);
+}
+__device__ __forceinline__ void pack_status(uint4& a, uint4& b, uint32_t status, uint32_t ref_row) {
+    pack_result(a, b, status, 0, BLU_NONE_U8, BLU_NONE_U8, BLU_NONE_U16, BLU_NONE_U16, 0xFFFFFFFFu, ref_row, 0ull, 0.0);
+}
 __device__ __forceinline__ void store_status(blu_result* out, uint64_t q, uint32_t status, uint32_t ref_row) {
     store_result(out, q, status, 0, BLU_NONE_U8, BLU_NONE_U8, BLU_NONE_U16, BLU_NONE_U16, 0xFFFFFFFFu, ref_row, 0ull, 0.0);
 }
@@ -187,16 +202,21 @@ static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 // the five hit columns are read exactly once per run: non-temporal loads keep them from displacing the
 // lineage rows and cutoff tables (re-read by every query) in L2 / Infinity Cache
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifdef BLU_EXP_NO_NT
 #define STREAM_AUX 0
 #else
 #define STREAM_AUX 2   // nt
 #endif
+#ifndef RECORD_AUX
+#define RECORD_AUX 18  // sc1 | nt
+#endif
 
 struct WaveLds {
     Entry list[LIST_CAP];       // top-group rows of the task's queries, file order
     uint32_t hdr[LIST_CAP];     // lineage header (len | shape << 8); 0 = unmatched taxid (pos 0xFFFFFFFF) or bad lineage
-    uint32_t meta[WAVE];        // first entry | k << 16 | META_SLOW
+    uint32_t meta[WAVE + 4];    // first entry | k << 16, or META_SLOW
+    uint2 seg[WAVE + 4];        // {first row relative to the task's first row, row count (0 if > 64)}
 };
 
 template <int STRAT>
@@ -227,7 +247,6 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
         // column, based at the task's first row: 32-bit lane offsets, no 64-bit VALU address math, and the
         // hardware range check returns 0 for lanes that run past the end of the table.
         const uint64_t task_start = rl_u64(my_off, 0);
-        const uint32_t rel_off = (uint32_t)(my_off - task_start), rel_end = (uint32_t)(my_end - task_start);
         const uint64_t rem = h.n_hits - task_start;
         const uint32_t rem4 = (uint32_t)(rem * 4 > 0xFFFFFFFFull ? 0xFFFFFFFFull : rem * 4);
         const uint32_t rem8 = (uint32_t)(rem * 8 > 0xFFFFFFFFull ? 0xFFFFFFFFull : rem * 8);
@@ -236,91 +255,140 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
         const auto rs_aln = __builtin_amdgcn_make_buffer_rsrc((void*)(h.align_len + task_start), 0, rem4, 0x00020000);
         const auto rs_acc = __builtin_amdgcn_make_buffer_rsrc((void*)(h.acc_rank + task_start), 0, rem4, 0x00020000);
         const auto rs_pid = __builtin_amdgcn_make_buffer_rsrc((void*)(h.pident + task_start), 0, rem8, 0x00020000);
-        // ---------------- phase 1: lane = hit ----------------
-        uint2 g_inf[BATCH];                    // {header, pos} gathers of the previous batch, written to LDS one batch later
-        uint32_t g_idx[BATCH];
+        // per-query {first row, row count} of the task, relative to task_start; count 0 also for segments > 64 rows
+        // (those go to the worklist in phase 2a) so that phase 1 simply finds no top row in them
+        {
+            const uint64_t nrows = my_end - my_off;
+            L.seg[lane] = make_uint2((uint32_t)(my_off - task_start), nrows <= WAVE ? (uint32_t)nrows : 0u);
+        }
+        // ---------------- phase 1: 4 queries per step, 16 lanes per query, 4 consecutive rows per lane ----------------
+        const uint32_t grp = (uint32_t)lane >> 4, sub4 = ((uint32_t)lane & 15u) * 4u;
+        uint2 g_inf[4];      // {header, pos} gathers of the previous step, written to LDS one step later
+        uint32_t g_idx[4];
 #pragma unroll
-        for (int u = 0; u < BATCH; ++u) { g_inf[u] = make_uint2(0u, 0xFFFFFFFFu); g_idx[u] = 0xFFFFFFFFu; }
-        for (uint32_t qb = 0; qb < nq; qb += BATCH) {
-            int bs[BATCH];
-            uint32_t tax[BATCH], aln[BATCH], acc[BATCH], n[BATCH];
-            double pid[BATCH];
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const uint32_t qi = qb + u < nq ? qb + u : nq - 1;   // tail: re-read the last query, result discarded
-                const uint32_t so = (uint32_t)rl((int)rel_off, (int)qi);
-                n[u] = (uint32_t)rl((int)rel_end, (int)qi) - so;
-                // unconditional loads (lanes past the segment read the next query's rows or get 0 past the table):
-                // no VALU write touches a register with a load in flight, so no wait is needed before issuing
-                const uint32_t voff = (so + (uint32_t)lane) * 4u;
-                bs[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_bs, voff, 0, STREAM_AUX);
-                tax[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_tax, voff, 0, STREAM_AUX);
-                const u32x2 pw = __builtin_amdgcn_raw_buffer_load_b64(rs_pid, voff * 2u, 0, STREAM_AUX);
-                pid[u] = __hiloint2double((int)pw.y, (int)pw.x);
-                aln[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_aln, voff, 0, STREAM_AUX);
-                acc[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_acc, voff, 0, STREAM_AUX);
+        for (int r = 0; r < 4; ++r) { g_inf[r] = make_uint2(0u, 0xFFFFFFFFu); g_idx[r] = 0xFFFFFFFFu; }
+        for (uint32_t qb = 0; qb < nq; qb += 4) {
+            const uint32_t qi = qb + grp;                        // this lane's query (>= nq: empty slot of the table)
+            const uint2 sg = L.seg[qi];
+            const int left = (int)sg.y - (int)sub4;              // rows of the segment from this lane's first row on
+            const uint32_t voff = (sg.x + sub4) * 4u;
+#ifndef BLU_EXP_UNCOND_LOADS
+            // lanes past the end of the segment issue nothing (a few % fewer L1 requests than reading on into the
+            // next query's rows); their registers stay undefined and are masked by `left` below
+            u32x4 vbs, vtax, vp01, vp23, valn, vacc;
+            if (left > 0) {
+                vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
+                vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, voff, 0, STREAM_AUX);
+                vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u, 0, STREAM_AUX);
+                vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u + 16u, 0, STREAM_AUX);
+                valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, voff, 0, STREAM_AUX);
+                vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, voff, 0, STREAM_AUX);
             }
-            // headers gathered during the previous batch have landed by now (they are older than this batch's loads)
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u)
-                if (g_idx[u] != 0xFFFFFFFFu) { L.hdr[g_idx[u]] = g_inf[u].x; L.list[g_idx[u]].pos = g_inf[u].y; }
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                g_idx[u] = 0xFFFFFFFFu;
-                // Every loaded register is read here on every path, so that no load of this batch is still
-                // "possibly in flight" at the loop back-edge (the compiler would otherwise park a vmcnt(0)
-                // at the loop head, in front of the next batch's loads and behind this batch's header gathers).
-                asm volatile("" ::"v"(bs[u]), "v"(tax[u]), "v"(aln[u]), "v"(acc[u]), "v"(pid[u]));
-                if (qb + u >= nq) continue;
-                uint32_t m = 0;
-                if (n[u] >= 1 && n[u] <= WAVE) {
-                    const bool act = (uint32_t)lane < n[u];
-                    const int M = wave_max_i32(act ? bs[u] : INT_MIN);
-                    const uint64_t mask = __ballot(act && bs[u] == M);
-                    const uint32_t k = (uint32_t)__builtin_popcountll(mask);
-                    if (fill + k > LIST_CAP) m = META_SLOW;
-                    else {
-                        if ((mask >> lane) & 1) {
-                            const uint32_t idx = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                            Entry e;
-                            e.pos = 0xFFFFFFFFu; e.aln = aln[u]; e.acc = acc[u]; e.pq = (uint32_t)lane | ((qb + u) << 8); e.pid = pid[u];
-                            L.list[idx] = e;
-                            g_idx[u] = idx;
-                            // 8 bytes per taxid {header, sorted position}: the only taxonomy data phase 1 touches
-#ifdef BLU_EXP_P1ONLY
-                            g_inf[u] = make_uint2(tax[u], tax[u]);
 #else
-                            g_inf[u] = tax[u] < t.n_tax ? t.info[tax[u]] : make_uint2(0u, 0xFFFFFFFFu);
+            // unconditional 16-byte loads (lanes past the segment read the next query's rows, or 0 past the table):
+            // no VALU write touches a register with a load in flight, so nothing waits in front of the issue
+            const u32x4 vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
+            const u32x4 vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, voff, 0, STREAM_AUX);
+            const u32x4 vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u, 0, STREAM_AUX);
+            const u32x4 vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u + 16u, 0, STREAM_AUX);
+            const u32x4 valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, voff, 0, STREAM_AUX);
+            const u32x4 vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, voff, 0, STREAM_AUX);
 #endif
-                        }
-                        m = fill | (k << 16);
-                        fill += k;
-                    }
+            // the {header, pos} gathers of the previous step are older than these loads: they have landed by the
+            // time this step's data is used, so writing them out here never stalls
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (g_idx[r] != 0xFFFFFFFFu) { L.hdr[g_idx[r]] = g_inf[r].x; L.list[g_idx[r]].pos = g_inf[r].y; }
+            // every loaded register is read here on every path (see the note on vmcnt at the loop head)
+            asm volatile("" ::"v"(vbs), "v"(vtax), "v"(vp01), "v"(vp23), "v"(valn), "v"(vacc));
+#ifdef BLU_EXP_NOREDUCE
+            continue;
+#endif
+            const int b0 = left > 0 ? (int)vbs.x : INT_MIN, b1 = left > 1 ? (int)vbs.y : INT_MIN;
+            const int b2 = left > 2 ? (int)vbs.z : INT_MIN, b3 = left > 3 ? (int)vbs.w : INT_MIN;
+            int M = imax(imax(b0, b1), imax(b2, b3));
+            ROW_REDUCE(M, imax)                                   // 16-lane rows: M = the query's top bit-score
+            const bool t0 = left > 0 && b0 == M, t1 = left > 1 && b1 == M, t2 = left > 2 && b2 == M, t3 = left > 3 && b3 == M;
+            const uint32_t c = (uint32_t)t0 + (uint32_t)t1 + (uint32_t)t2 + (uint32_t)t3;
+            uint32_t incl = c;                                    // inclusive prefix of the top-row counts inside the 16-lane row
+            incl += (uint32_t)dpp<0x111>((int)incl);
+            incl += (uint32_t)dpp<0x112>((int)incl);
+            incl += (uint32_t)dpp<0x114>((int)incl);
+            incl += (uint32_t)dpp<0x118>((int)incl);
+            const uint32_t k0 = (uint32_t)rl((int)incl, 15), k1 = (uint32_t)rl((int)incl, 31);
+            const uint32_t k2 = (uint32_t)rl((int)incl, 47), k3 = (uint32_t)rl((int)incl, 63);
+            const bool fits = fill + k0 + k1 + k2 + k3 <= LIST_CAP;   // else: the four queries go to the worklist
+            const uint32_t p1 = fill + k0, p2 = p1 + k1, p3 = p2 + k2;
+            const uint32_t gbase = grp == 0 ? fill : (grp == 1 ? p1 : (grp == 2 ? p2 : p3));
+            const uint32_t gk = grp == 0 ? k0 : (grp == 1 ? k1 : (grp == 2 ? k2 : k3));
+            if (((uint32_t)lane & 15u) == 0) L.meta[qi] = fits ? (gbase | (gk << 16)) : META_SLOW;
+            uint32_t idx = gbase + incl - c;                      // list slot of this lane's first top row (file order)
+            const bool tt[4] = {t0, t1, t2, t3};
+            const uint32_t xt[4] = {vtax.x, vtax.y, vtax.z, vtax.w}, xa[4] = {valn.x, valn.y, valn.z, valn.w};
+            const uint32_t xc[4] = {vacc.x, vacc.y, vacc.z, vacc.w};
+            const double xp[4] = {__hiloint2double((int)vp01.y, (int)vp01.x), __hiloint2double((int)vp01.w, (int)vp01.z),
+                                  __hiloint2double((int)vp23.y, (int)vp23.x), __hiloint2double((int)vp23.w, (int)vp23.z)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                g_idx[r] = 0xFFFFFFFFu;
+#ifdef BLU_EXP_NOLDS
+                if (false) {
+#else
+                if (fits && tt[r]) {
+#endif
+                    Entry e;
+                    e.pos = 0xFFFFFFFFu; e.aln = xa[r]; e.acc = xc[r]; e.pq = (sub4 + r) | (qi << 8); e.pid = xp[r];
+                    L.list[idx] = e;
+                    g_idx[r] = idx;
+                    // 8 bytes per taxid {header, sorted position}: the only taxonomy data phase 1 touches
+#ifdef BLU_EXP_P1ONLY
+                    g_inf[r] = make_uint2(xt[r], xt[r]);
+#else
+                    g_inf[r] = xt[r] < t.n_tax ? t.info[xt[r]] : make_uint2(0u, 0xFFFFFFFFu);
+#endif
+                    ++idx;
                 }
-                if (lane == 0) L.meta[qb + u] = m;
             }
+            if (fits) fill = p3 + k3;
         }
 #pragma unroll
-        for (int u = 0; u < BATCH; ++u)
-            if (g_idx[u] != 0xFFFFFFFFu) { L.hdr[g_idx[u]] = g_inf[u].x; L.list[g_idx[u]].pos = g_inf[u].y; }
+        for (int r = 0; r < 4; ++r)
+            if (g_idx[r] != 0xFFFFFFFFu) { L.hdr[g_idx[r]] = g_inf[r].x; L.list[g_idx[r]].pos = g_inf[r].y; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
+#ifdef BLU_EXP_NOSTORE
+        continue;
+#endif
 #ifdef BLU_EXP_P1ONLY
-        if ((uint32_t)lane < nq) store_status(out, q0 + (uint32_t)lane, 2, L.hdr[L.meta[lane] & 0xFF] + (uint32_t)L.list[L.meta[lane] & 0xFF].pid + L.list[L.meta[lane] & 0xFF].pos);
+        {
+            uint4 pa, pb;
+            pack_status(pa, pb, 2, L.hdr[L.meta[lane] & 0xFF] + (uint32_t)L.list[L.meta[lane] & 0xFF].pid + L.list[L.meta[lane] & 0xFF].pos);
+            __builtin_amdgcn_wave_barrier();
+            uint4* rec = reinterpret_cast<uint4*>(L.list);
+            rec[2 * lane] = pa; rec[2 * lane + 1] = pb;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint4* dst = reinterpret_cast<uint4*>(out + q0);
+            for (int half = 0; half < 2; ++half) { const uint32_t c = (uint32_t)lane + 64u * half; if ((c >> 1) < nq) dst[c] = rec[c]; }
+            __builtin_amdgcn_wave_barrier();
+        }
         continue;
 #endif
         // ---------------- phase 2a: lane = query, LDS only ----------------
         // mode: 0 multi, 2 single, 3 finished (empty / error / handed to the worklist)
         const uint64_t q = q0 + (uint32_t)lane;
         const uint32_t row0 = (uint32_t)my_off;
-        uint32_t mode = 3, r_hdr = 0, r_row = 0, r_pos = 0, minlen = 0, d = 0;
+        // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
+        uint32_t mode = 3, r_hdr = 0, r_row = 0, r_pos = 0, minlen = 0, d = 0, rec_kind = 0;
         double r_pid = 0.0, max_pid = 0.0;
+        uint4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
         if ((uint32_t)lane < nq) {
             const uint64_t nrows = my_end - my_off;
             const uint32_t m = L.meta[lane];
-            if (nrows == 0) store_status(out, q, BLU_ST_NO_HITS, 0xFFFFFFFFu);            // mod.rs:107-113
+            if (nrows == 0) { pack_status(ra, rb, BLU_ST_NO_HITS, 0xFFFFFFFFu); rec_kind = 1; }   // mod.rs:107-113
             else if (nrows > WAVE || (m & META_SLOW)) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
             else {
                 const uint32_t first = m & 0xFFFF, k = (m >> 16) & 0xFF;
@@ -338,7 +406,7 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                         const double p = L.list[first + e].pid;
                         if (err == 0 && p != p) { err = BLU_ST_ERR_BAD_PIDENT; err_pos = L.list[first + e].pq & 0xFF; }
                     }
-                if (err) store_status(out, q, err, row0 + err_pos);
+                if (err) { pack_status(ra, rb, err, row0 + err_pos); rec_kind = 1; }
                 else {
                     // reference row, shortest lineage, group-max pident (find_multi_taxa_consensus.rs:39-68,142-145,182-185)
                     // and the span [lo, hi] of the group in the sorted lineage order
@@ -372,14 +440,15 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
 
         // ---------------- phase 2c: lane = query, cutoff tests and the record ----------------
 #ifdef BLU_EXP_SKIP_2C
-        if (mode != 3) store_status(out, q, mode, r_row + minlen + d + r_pos + r_hdr);
+        if (mode != 3) { pack_status(ra, rb, mode, r_row + minlen + d + r_pos + r_hdr); rec_kind = 1; }
         if (false) {
 #else
         if (mode != 3) {
 #endif
             const bool single = mode == 2;
             const bool agree = single | (d >= minlen);
-            if (!agree && d == 0) store_status(out, q, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
+            rec_kind = 1;
+            if (!agree && d == 0) pack_status(ra, rb, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
             else {
                 const uint32_t len_ref = r_hdr & 0xFF, shape = r_hdr >> 8;
                 const uint32_t b = single ? len_ref : (agree ? minlen - 1 : d - 1);
@@ -408,12 +477,16 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                     }
                 }
                 if (agree) A = F;                                                  // single hit / single-flag branch (:74-75)
+#ifdef BLU_EXP_NOREF
+                const uint32_t* ref = t.lin;
+#else
                 const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
+#endif
                 if (single) {
-                    if (!A) store_status(out, q, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, row0 + r_pos);   // find_single_query_consensus.rs:113-119
+                    if (!A) pack_status(ra, rb, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, row0 + r_pos);   // find_single_query_consensus.rs:113-119
                     else {
                         const uint32_t last = (uint32_t)last_lane(A);
-                        store_result(out, q, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, codes[last] & 0xFFFF, BLU_NONE_U16,
+                        pack_result(ra, rb, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, codes[last] & 0xFFFF, BLU_NONE_U16,
                                      ref[1 + last], row0 + r_pos, A, ident);
                     }
                 } else {
@@ -423,9 +496,34 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                         mar_code = codes[mar_level] >> 16;
                         if (mar_code != (codes[b] & 0xFFFF)) flags |= BLU_FLAG_MUTATED;   // bean.reached_rank != allowed_rank (:35-37)
                     }
-                    store_result(out, q, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, codes[last] & 0xFFFF, mar_code,
+                    pack_result(ra, rb, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, codes[last] & 0xFFFF, mar_code,
                                  ref[1 + last], row0 + r_pos, A, ident);
                 }
+            }
+        }
+        // ---------------- records: staged through LDS, stored as two fully coalesced 1 KiB rows ----------------
+        // (a 32-byte record per lane straight to memory is 64 scattered 16-byte pieces per store instruction;
+        // measured: 0.7 ms of a 2.7 ms launch.)  The list area is dead after phase 2a and is reused.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        uint4* rec = reinterpret_cast<uint4*>(L.list);
+        rec[2 * lane] = ra;
+        rec[2 * lane + 1] = rb;
+        L.meta[lane] = rec_kind;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // write-through + non-temporal (sc1 nt): a record is written once and never read by the GPU; letting the
+        // lines sit dirty in L2 until the read stream evicts them one by one costs ~2x more HBM time (probe:
+        // scripts/probe/pattern_probe.hip store modes 1 vs 18)
+        const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + q0), 0, nq * 32u, 0x00020000);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t c = (uint32_t)lane + 64u * half, qc = c >> 1;
+            if (qc < nq && L.meta[qc]) {
+                const uint4 v = rec[c];
+                const u32x4 w = {v.x, v.y, v.z, v.w};
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, c * 16u, 0, RECORD_AUX);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

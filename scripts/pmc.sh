@@ -6,7 +6,7 @@ out=$1; shift; mkdir -p $out
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-include-regex "blu_" --output-format csv -d $out/pass$i -- \
+  timeout -k 10 150 rocprofv3 --pmc $grp --kernel-include-regex "blu_" --output-format csv -d $out/pass$i -- \
      python3 bench.py --steps 3 --warmup 1 --no-parity-gate --no-cpu-baseline $PMC_BENCH_ARGS > $out/pass$i.json 2> $out/pass$i.log
   echo "pass $i ($grp) rc=$?"
 done
