@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("BLU_CONSENSUS_LIB") or os.path.join(_HERE, "lib", "li
 EXPORTS = (
     "blu_abi_version", "blu_last_error", "blu_taxonomy_create", "blu_taxonomy_destroy", "blu_taxonomy_n_tax",
     "blu_taxonomy_n_shapes", "blu_taxonomy_n_rank_codes", "blu_taxonomy_max_depth", "blu_taxonomy_device_bytes",
-    "blu_taxonomy_rank_name", "blu_taxonomy_row_cutoffs", "blu_taxonomy_lookup", "blu_consensus_run",
+    "blu_taxonomy_rank_name", "blu_taxonomy_row_cutoffs", "blu_taxonomy_lookup", "blu_taxonomy_row_map", "blu_consensus_run",
     "blu_consensus_last_launch",
 )
 
@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
     L.blu_taxonomy_row_cutoffs.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.blu_taxonomy_lookup.restype = C.c_int
     L.blu_taxonomy_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.blu_taxonomy_row_map.restype = C.c_int
+    L.blu_taxonomy_row_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.blu_consensus_run.restype = C.c_int
     L.blu_consensus_run.argtypes = [C.c_void_p, C.POINTER(Hits), C.POINTER(RunParams), C.c_void_p]
     L.blu_consensus_last_launch.restype = C.c_int

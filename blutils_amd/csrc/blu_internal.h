@@ -27,8 +27,11 @@ struct TaxDev {
     // Lineage rows in LEXICOGRAPHIC order of their node sequences (row index = "pos"):
     // word0 = len | shape << 8 (len 0 = bad lineage), words 1.. = node ids, root -> leaf.
     const uint32_t* lin;    // [n_tax][stride]
-    // caller's tax_row -> {header word, pos}; 8 bytes per taxid, the only table the streaming phase touches
-    const uint2* info;      // [n_tax]
+    // engine row ids (blu_hits.tax_row) ARE these sorted positions.  Per row, one byte of lineage length
+    // (0 = bad lineage) — the only taxonomy data the streaming phase touches, 2.4 MB for 2.4 M taxids,
+    // L2-resident — and the rank-sequence shape id, read once per query for the reference row.
+    const uint8_t* len8;    // [n_tax]
+    const uint32_t* shape;  // [n_tax]
     // lcp8[i] = number of leading levels shared by sorted rows i and i+1.  In that order the levels shared by a
     // whole group of rows = min(lcp8[lo .. hi-1]) for the group's smallest/largest pos: a range-minimum query
     // replaces the per-row level scan of find_multi_taxa_consensus.rs:137-180.
@@ -80,7 +83,9 @@ struct blu_taxonomy {
     uint32_t n_shapes = 0;
     std::unordered_map<int64_t, uint32_t> taxid_row;
     uint32_t* d_lin = nullptr;
-    uint2* d_info = nullptr;
+    uint8_t* d_len8 = nullptr;
+    uint32_t* d_shape = nullptr;
+    std::vector<uint32_t> order;             // engine row id -> desc row
     uint8_t* d_lcp8 = nullptr;
     uint8_t* d_rmq = nullptr;
     uint32_t rmq_nb = 0;

@@ -193,7 +193,7 @@ __device__ __forceinline__ uint32_t shared_levels(const TaxDev& t, uint32_t lo, 
 // Kernel A
 // ===============================================================================
 struct Entry {            // one top-group row in LDS, 24 bytes
-    uint32_t pos, aln, acc, pq;   // pos = sorted position of the row's lineage; pq = position in the segment | query-in-task << 8
+    uint32_t pos, aln, acc, pq;   // pos = engine row id (sorted lineage position); pq = position in the segment | query-in-task << 8
     double pid;
 };
 static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
@@ -203,10 +203,13 @@ static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 // lineage rows and cutoff tables (re-read by every query) in L2 / Infinity Cache
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#ifdef BLU_EXP_NO_NT
-#define STREAM_AUX 0
+// Plain (not nt) loads for the five columns: a 128-byte line is shared by consecutive queries (50 hits = 200 B per
+// 4-byte column), and with nt the line is dropped before the wave's next step needs its other half — measured
+// +12 % HBM read requests (TCC_EA0_RDREQ) and +10 % time.
+#ifdef BLU_EXP_NT
+#define STREAM_AUX 2
 #else
-#define STREAM_AUX 2   // nt
+#define STREAM_AUX 0
 #endif
 #ifndef RECORD_AUX
 #define RECORD_AUX 18  // sc1 | nt
@@ -214,7 +217,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct WaveLds {
     Entry list[LIST_CAP];       // top-group rows of the task's queries, file order
-    uint32_t hdr[LIST_CAP];     // lineage header (len | shape << 8); 0 = unmatched taxid (pos 0xFFFFFFFF) or bad lineage
+    uint32_t len[LIST_CAP];     // lineage length of list[i].pos; 0 = unmatched taxid (pos >= n_tax) or bad lineage
     uint32_t meta[WAVE + 4];    // first entry | k << 16, or META_SLOW
     uint2 seg[WAVE + 4];        // {first row relative to the task's first row, row count (0 if > 64)}
 };
@@ -263,10 +266,10 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
         }
         // ---------------- phase 1: 4 queries per step, 16 lanes per query, 4 consecutive rows per lane ----------------
         const uint32_t grp = (uint32_t)lane >> 4, sub4 = ((uint32_t)lane & 15u) * 4u;
-        uint2 g_inf[4];      // {header, pos} gathers of the previous step, written to LDS one step later
+        uint32_t g_len[4];   // lineage-length gathers of the previous step, written to LDS one step later
         uint32_t g_idx[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { g_inf[r] = make_uint2(0u, 0xFFFFFFFFu); g_idx[r] = 0xFFFFFFFFu; }
+        for (int r = 0; r < 4; ++r) { g_len[r] = 0; g_idx[r] = 0xFFFFFFFFu; }
         for (uint32_t qb = 0; qb < nq; qb += 4) {
             const uint32_t qi = qb + grp;                        // this lane's query (>= nq: empty slot of the table)
             const uint2 sg = L.seg[qi];
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
             // time this step's data is used, so writing them out here never stalls
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (g_idx[r] != 0xFFFFFFFFu) { L.hdr[g_idx[r]] = g_inf[r].x; L.list[g_idx[r]].pos = g_inf[r].y; }
+                if (g_idx[r] != 0xFFFFFFFFu) L.len[g_idx[r]] = g_len[r];
             // every loaded register is read here on every path (see the note on vmcnt at the loop head)
             asm volatile("" ::"v"(vbs), "v"(vtax), "v"(vp01), "v"(vp23), "v"(valn), "v"(vacc));
 #ifdef BLU_EXP_NOREDUCE
@@ -337,14 +340,14 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                 if (fits && tt[r]) {
 #endif
                     Entry e;
-                    e.pos = 0xFFFFFFFFu; e.aln = xa[r]; e.acc = xc[r]; e.pq = (sub4 + r) | (qi << 8); e.pid = xp[r];
+                    e.pos = xt[r]; e.aln = xa[r]; e.acc = xc[r]; e.pq = (sub4 + r) | (qi << 8); e.pid = xp[r];
                     L.list[idx] = e;
                     g_idx[r] = idx;
-                    // 8 bytes per taxid {header, sorted position}: the only taxonomy data phase 1 touches
+                    // one byte per taxid (lineage length): the only taxonomy data phase 1 touches
 #ifdef BLU_EXP_P1ONLY
-                    g_inf[r] = make_uint2(xt[r], xt[r]);
+                    g_len[r] = xt[r];
 #else
-                    g_inf[r] = xt[r] < t.n_tax ? t.info[xt[r]] : make_uint2(0u, 0xFFFFFFFFu);
+                    g_len[r] = xt[r] < t.n_tax ? (uint32_t)t.len8[xt[r]] : 0u;
 #endif
                     ++idx;
                 }
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (g_idx[r] != 0xFFFFFFFFu) { L.hdr[g_idx[r]] = g_inf[r].x; L.list[g_idx[r]].pos = g_inf[r].y; }
+            if (g_idx[r] != 0xFFFFFFFFu) L.len[g_idx[r]] = g_len[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
 #ifdef BLU_EXP_P1ONLY
         {
             uint4 pa, pb;
-            pack_status(pa, pb, 2, L.hdr[L.meta[lane] & 0xFF] + (uint32_t)L.list[L.meta[lane] & 0xFF].pid + L.list[L.meta[lane] & 0xFF].pos);
+            pack_status(pa, pb, 2, L.len[L.meta[lane] & 0xFF] + (uint32_t)L.list[L.meta[lane] & 0xFF].pid + L.list[L.meta[lane] & 0xFF].pos);
             __builtin_amdgcn_wave_barrier();
             uint4* rec = reinterpret_cast<uint4*>(L.list);
             rec[2 * lane] = pa; rec[2 * lane + 1] = pb;
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
         const uint64_t q = q0 + (uint32_t)lane;
         const uint32_t row0 = (uint32_t)my_off;
         // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
-        uint32_t mode = 3, r_hdr = 0, r_row = 0, r_pos = 0, minlen = 0, d = 0, rec_kind = 0;
+        uint32_t mode = 3, r_len = 0, r_row = 0, r_pos = 0, minlen = 0, d = 0, rec_kind = 0;
         double r_pid = 0.0, max_pid = 0.0;
         uint4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
         if ((uint32_t)lane < nq) {
@@ -395,9 +398,9 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                 // parse errors first, in file order (find_single_query_consensus.rs:51-64), then NaN pident
                 uint32_t err = 0, err_pos = 0;
                 for (uint32_t e = 0; e < k; ++e) {
-                    const uint32_t hd = L.hdr[first + e];
+                    const uint32_t hd = L.len[first + e];
                     if (err == 0 && hd == 0) {
-                        err = L.list[first + e].pos == 0xFFFFFFFFu ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE;
+                        err = L.list[first + e].pos >= t.n_tax ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE;
                         err_pos = L.list[first + e].pq & 0xFF;
                     }
                 }
@@ -415,17 +418,17 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                     minlen = 0xFFFFFFFFu;
                     for (uint32_t e = 0; e < k; ++e) {
                         const Entry x = L.list[first + e];
-                        const uint32_t hd = L.hdr[first + e], len = hd & 0xFF;
+                        const uint32_t len = L.len[first + e];
                         minlen = umin(minlen, len);
                         lo = umin(lo, x.pos);
                         hi = x.pos > hi ? x.pos : hi;
                         max_pid = x.pid > max_pid ? x.pid : max_pid;
                         const bool take = (e == 0) | key_better<STRAT>(len, x.pid, (int)x.aln, x.acc, b_len, r_pid, b_aln, b_acc);
                         b_len = take ? len : b_len;
+                        r_len = b_len;
                         r_pid = take ? x.pid : r_pid;
                         b_aln = take ? (int)x.aln : b_aln;
                         b_acc = take ? x.acc : b_acc;
-                        r_hdr = take ? hd : r_hdr;
                         r_row = take ? x.pos : r_row;
                         r_pos = take ? (x.pq & 0xFF) : r_pos;
                     }
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
 
         // ---------------- phase 2c: lane = query, cutoff tests and the record ----------------
 #ifdef BLU_EXP_SKIP_2C
-        if (mode != 3) { pack_status(ra, rb, mode, r_row + minlen + d + r_pos + r_hdr); rec_kind = 1; }
+        if (mode != 3) { pack_status(ra, rb, mode, r_row + minlen + d + r_pos + r_len); rec_kind = 1; }
         if (false) {
 #else
         if (mode != 3) {
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
             rec_kind = 1;
             if (!agree && d == 0) pack_status(ra, rb, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
             else {
-                const uint32_t len_ref = r_hdr & 0xFF, shape = r_hdr >> 8;
+                const uint32_t len_ref = r_len, shape = t.shape[r_row];
                 const uint32_t b = single ? len_ref : (agree ? minlen - 1 : d - 1);
                 const double ident = (single | agree) ? r_pid : max_pid;
                 const double* cut = t.cut + (uint64_t)shape * t.sc;
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
         const int M = wave_max_i32(m);
         // pass 2: group size, errors in file order, lane-local best key / shortest lineage / max pident
         uint32_t k = 0, err_status = 0, err_row = 0;
-        uint32_t have = 0, b_len = 0, b_acc = 0, b_pos = 0, b_row = 0, b_shape = 0, l_minlen = 0xFFFFFFFFu;
+        uint32_t have = 0, b_len = 0, b_acc = 0, b_pos = 0, b_row = 0, l_minlen = 0xFFFFFFFFu;
         uint32_t l_lo = 0xFFFFFFFFu, l_hi = 0;   // span of this lane's top rows in the sorted lineage order
         int b_aln = 0;
         double b_pid = 0.0, l_maxpid = 0.0;
@@ -608,8 +611,7 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             const int aln = c_aln[ii];
             const uint32_t acc = c_acc[ii];
             const bool unmatched = top && tax >= t.n_tax;
-            const uint2 inf = t.info[(top && !unmatched) ? tax : 0u];   // {header, sorted position}
-            const uint32_t hdr = inf.x, len = hdr & 0xFF;
+            const uint32_t len = t.len8[(top && !unmatched) ? tax : 0u];
             const bool bad = top && !unmatched && len == 0;
             const uint64_t um = __ballot(unmatched), bm = __ballot(bad);
             if (um | bm) {   // parse_taxonomy Err at the first failing row (find_single_query_consensus.rs:58-60)
@@ -625,11 +627,10 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             b_aln = take ? aln : b_aln;
             b_acc = take ? acc : b_acc;
             b_pos = take ? i : b_pos;
-            b_row = take ? inf.y : b_row;
-            b_shape = take ? (hdr >> 8) : b_shape;
+            b_row = take ? tax : b_row;
             l_minlen = top ? umin(l_minlen, len) : l_minlen;
-            l_lo = top ? umin(l_lo, inf.y) : l_lo;
-            l_hi = (top && inf.y > l_hi) ? inf.y : l_hi;
+            l_lo = top ? umin(l_lo, tax) : l_lo;
+            l_hi = (top && tax > l_hi) ? tax : l_hi;
             l_maxpid = (top && pid > l_maxpid) ? pid : l_maxpid;
         }
         if (err_status) {
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
         }
         const uint32_t row_ref = (uint32_t)rl((int)b_row, rlane);
         const uint32_t len_ref = (uint32_t)rl((int)b_len, rlane);
-        const uint32_t shape_ref = (uint32_t)rl((int)b_shape, rlane);
+        const uint32_t shape_ref = t.shape[row_ref];
         const uint32_t pos_ref = (uint32_t)rl((int)b_pos, rlane);
         const double pid_ref = rl_f64(b_pid, rlane);
         const bool in_l = (uint32_t)lane < len_ref;

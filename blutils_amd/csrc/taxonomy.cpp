@@ -283,8 +283,14 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
     std::vector<uint32_t> lin_sorted((size_t)n * stride);
     for (uint64_t i = 0; i < n; ++i)
         memcpy(&lin_sorted[(size_t)i * stride], L + (size_t)order[i] * stride, stride * sizeof(uint32_t));
-    std::vector<uint2> info(std::max<uint64_t>(n, 1));
-    for (uint64_t t = 0; t < n; ++t) info[t] = make_uint2(L[(size_t)t * stride], tax->pos_of[t]);
+    std::vector<uint8_t> len8(std::max<uint64_t>(n, 1) + 16, 0);
+    std::vector<uint32_t> shape_sorted(std::max<uint64_t>(n, 1), 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t hdr = lin_sorted[(size_t)i * stride];
+        len8[i] = (uint8_t)(hdr & 0xFF);
+        shape_sorted[i] = hdr >> 8;
+    }
+    tax->order = order;
     const uint64_t n_lcp = n > 0 ? n - 1 : 0;
     const uint32_t nb = (uint32_t)((n_lcp + 15) / 16) + 1;            // 16-entry blocks (+1 block of padding)
     std::vector<uint8_t> lcp8((size_t)nb * 16 + 16, 0xFF);
@@ -320,17 +326,19 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
         if (e == hipSuccess) tax->num_cus = prop.multiProcessorCount;
         size_t b_lin = std::max<size_t>(lin_sorted.size(), 16) * sizeof(uint32_t);
-        size_t b_info = info.size() * sizeof(uint2);
+        size_t b_len8 = len8.size(), b_shape = shape_sorted.size() * sizeof(uint32_t);
         size_t b_cut = tax->h_cut.size() * sizeof(double);
         size_t b_codes = tax->h_codes.size() * sizeof(uint32_t);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lin, b_lin);
-        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_info, b_info);
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_len8, b_len8);
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_shape, b_shape);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lcp8, lcp8.size());
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_rmq, rmq.size());
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_cut, b_cut);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_codes, b_codes);
         if (e == hipSuccess && !lin_sorted.empty()) e = hipMemcpy(tax->d_lin, lin_sorted.data(), lin_sorted.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(tax->d_info, info.data(), b_info, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(tax->d_len8, len8.data(), b_len8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(tax->d_shape, shape_sorted.data(), b_shape, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_lcp8, lcp8.data(), lcp8.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_rmq, rmq.data(), rmq.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_cut, tax->h_cut.data(), b_cut, hipMemcpyHostToDevice);
@@ -340,7 +348,7 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
             blu_taxonomy_destroy(tax);
             return BLU_ERR_HIP;
         }
-        tax->device_bytes = b_lin + b_info + lcp8.size() + rmq.size() + b_cut + b_codes;
+        tax->device_bytes = b_lin + b_len8 + b_shape + lcp8.size() + rmq.size() + b_cut + b_codes;
     }
     *out = tax;
     return BLU_OK;
@@ -351,7 +359,8 @@ void blu_taxonomy_destroy(blu_taxonomy* tax) {
     if (tax->device >= 0) {
         (void)hipSetDevice(tax->device);
         if (tax->d_lin) (void)hipFree(tax->d_lin);
-        if (tax->d_info) (void)hipFree(tax->d_info);
+        if (tax->d_len8) (void)hipFree(tax->d_len8);
+        if (tax->d_shape) (void)hipFree(tax->d_shape);
         if (tax->d_lcp8) (void)hipFree(tax->d_lcp8);
         if (tax->d_rmq) (void)hipFree(tax->d_rmq);
         if (tax->d_cut) (void)hipFree(tax->d_cut);
@@ -392,8 +401,15 @@ int blu_taxonomy_lookup(const blu_taxonomy* tax, const int64_t* taxid, uint64_t 
     if (tax->taxid_row.empty() && tax->n_tax) { set_error("taxonomy was created without taxids"); return BLU_ERR_INVALID_ARG; }
     for (uint64_t i = 0; i < n; ++i) {
         auto it = tax->taxid_row.find(taxid[i]);
-        out_row[i] = it == tax->taxid_row.end() ? BLU_UNMATCHED_TAXID : it->second;
+        out_row[i] = it == tax->taxid_row.end() ? BLU_UNMATCHED_TAXID : tax->pos_of[it->second];
     }
+    return BLU_OK;
+}
+
+int blu_taxonomy_row_map(const blu_taxonomy* tax, uint32_t* out_map, uint32_t* out_inverse) {
+    if (!tax) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    if (out_map) memcpy(out_map, tax->pos_of.data(), tax->pos_of.size() * sizeof(uint32_t));
+    if (out_inverse) memcpy(out_inverse, tax->order.data(), tax->order.size() * sizeof(uint32_t));
     return BLU_OK;
 }
 

@@ -104,6 +104,36 @@ class Taxonomy:
             raise IndexError(row)
         return cut[:n], isdef[:n].astype(bool), codes[:n]
 
+    def row_map(self):
+        """(desc row -> engine row id, engine row id -> desc row).  Engine row ids (what blu_hits.tax_row holds)
+        number the taxonomy rows in lexicographic lineage order."""
+        if getattr(self, "_row_map", None) is None:
+            fwd = np.zeros(max(1, self.n_tax), dtype=np.uint32)
+            inv = np.zeros(max(1, self.n_tax), dtype=np.uint32)
+            rc = N.lib().blu_taxonomy_row_map(self._h, fwd.ctypes.data, inv.ctypes.data)
+            if rc != N.BLU_OK:
+                raise N.BluError(rc, "blu_taxonomy_row_map")
+            self._row_map = (fwd[: self.n_tax], inv[: self.n_tax])
+        return self._row_map
+
+    def engine_rows(self, desc_rows):
+        """desc row indices (numpy, or a torch tensor on any device; -1 / 0xFFFFFFFF = unmatched) -> engine row ids."""
+        fwd, _ = self.row_map()
+        if isinstance(desc_rows, np.ndarray):
+            r = desc_rows.view(np.uint32) if desc_rows.dtype == np.int32 else desc_rows.astype(np.uint32)
+            ok = r < self.n_tax
+            out = np.full(r.shape, N.BLU_UNMATCHED_TAXID, dtype=np.uint32)
+            out[ok] = fwd[r[ok]]
+            return out
+        import torch
+        key = str(desc_rows.device)
+        cache = self.__dict__.setdefault("_row_map_t", {})
+        if key not in cache:
+            cache[key] = torch.from_numpy(fwd.astype(np.int64)).to(torch.int32).to(desc_rows.device)   # ids < 2^31
+        m = cache[key]
+        ok = (desc_rows >= 0) & (desc_rows < self.n_tax)
+        return torch.where(ok, m[desc_rows.clamp(min=0, max=max(0, self.n_tax - 1)).long()], torch.full_like(desc_rows, -1))
+
     def lookup(self, taxids) -> np.ndarray:
         t = np.ascontiguousarray(taxids, dtype=np.int64)
         out = np.zeros(len(t), dtype=np.uint32)
@@ -126,7 +156,7 @@ class Taxonomy:
 
 def run_consensus_host(tax: Taxonomy, seg_off, bitscore, tax_row, pident, align_len, acc_rank,
                        strategy: str = "relaxed") -> np.ndarray:
-    """Host buffers in, host records out; the library stages them over PCIe."""
+    """Host buffers in, host records out; the library stages them over PCIe.  tax_row: ENGINE row ids."""
     seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
     bs = np.ascontiguousarray(bitscore, dtype=np.int32)
     tx = np.ascontiguousarray(tax_row)

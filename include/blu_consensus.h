@@ -86,7 +86,9 @@ typedef struct blu_taxonomy blu_taxonomy; /* opaque; owns the device copy */
  * coordinate columns are dead inputs and are not part of the layout. */
 typedef struct blu_hits {
     const int32_t* bitscore;   /* [n_hits] bit_score truncated toward zero to integer (mod.rs:184) */
-    const uint32_t* tax_row;   /* [n_hits] row in the taxonomy table or BLU_UNMATCHED_TAXID */
+    const uint32_t* tax_row;   /* [n_hits] ENGINE row id of subject_taxid (blu_taxonomy_lookup / blu_taxonomy_row_map:
+                                  the left join of mod.rs:72-76) or BLU_UNMATCHED_TAXID.  Engine row ids number the
+                                  taxonomy rows in lexicographic lineage order; they are NOT the desc row indices. */
     const double* pident;      /* [n_hits] perc_identity */
     const int32_t* align_len;  /* [n_hits] */
     const uint32_t* acc_rank;  /* [n_hits] order-preserving rank of subject_accession (bytewise String::cmp) */
@@ -165,10 +167,14 @@ const char* blu_taxonomy_rank_name(const blu_taxonomy* tax, uint32_t rank_code, 
 /* cutoffs of one taxonomy row: writes up to cap entries, returns the lineage length
  * (0 for a bad lineage, -1 for an invalid row). is_default[j]=1: level j mapped to a
  * DefaultRank of the backbone.  rank_code[j]: canonical code of level j. */
-int32_t blu_taxonomy_row_cutoffs(const blu_taxonomy* tax, uint64_t tax_row, uint32_t cap, double* cutoff,
+int32_t blu_taxonomy_row_cutoffs(const blu_taxonomy* tax, uint64_t desc_row, uint32_t cap, double* cutoff,
                                  uint8_t* is_default, uint16_t* rank_code);
-/* taxid -> taxonomy row (BLU_UNMATCHED_TAXID when absent); needs desc.taxid at create. */
+/* taxid -> ENGINE row id (BLU_UNMATCHED_TAXID when absent); needs desc.taxid at create.  This is the join of
+ * the hit table with the taxonomy (mod.rs:72-76); its output is what blu_hits.tax_row holds. */
 int blu_taxonomy_lookup(const blu_taxonomy* tax, const int64_t* taxid, uint64_t n, uint32_t* out_row);
+/* desc row index -> engine row id for every row of the table (out_map[n_tax]); inverse in out_inverse[n_tax]
+ * (either may be NULL).  For callers that already hold desc row indices. */
+int blu_taxonomy_row_map(const blu_taxonomy* tax, uint32_t* out_map, uint32_t* out_inverse);
 
 /* The hot path: one blu_result per query.  `out` has n_queries records, on the
  * device when hits->on_device, else on the host.  Asynchronous on

@@ -25,7 +25,8 @@ def _engine_tax(tax, taxon, custom=None, bad=None):
 
 
 def _run_host(t, hits, strategy):
-    return engine.run_consensus_host(t, hits["seg_off"], hits["bitscore"], hits["tax_row"], hits["pident"],
+    # hits["tax_row"] holds desc row indices (what the oracle reads); the engine takes its own row ids
+    return engine.run_consensus_host(t, hits["seg_off"], hits["bitscore"], t.engine_rows(hits["tax_row"]), hits["pident"],
                                      hits["align_len"], hits["acc_rank"], strategy=strategy)
 
 
@@ -67,10 +68,12 @@ def test_c2_100k_by_50(strategy):
     dh = synth.make_hits(tax, 100000, synth.SEEDS["C2"], 50, device="cuda")
     t = _engine_tax(tax, "custom", H.CUSTOM_16S)
     out = torch.zeros(32 * dh.n_queries, dtype=torch.uint8, device="cuda")
-    engine.run_consensus_device(t, dh.as_dict(), out, strategy=strategy)
+    hits = dh.numpy()
+    dev_hits = dh.as_dict()
+    dev_hits["tax_row"] = t.engine_rows(dev_hits["tax_row"]).contiguous()
+    engine.run_consensus_device(t, dev_hits, out, strategy=strategy)
     torch.cuda.synchronize()
     got = engine.records_from_tensor(out)
-    hits = dh.numpy()
     # the generator is counter-based integer arithmetic: the CPU copy of the same seed is the same table
     cpu = synth.make_hits(tax, 100000, synth.SEEDS["C2"], 50, device="cpu").numpy()
     for k in hits:
@@ -160,7 +163,7 @@ def test_golden_vectors_through_the_gpu(golden_dir, strategy):
     acc_sorted = sorted(range(len(tab.accessions)), key=lambda i: tab.accessions[i].encode())
     acc_rank = np.zeros(len(tab.accessions), dtype=np.uint32)
     acc_rank[acc_sorted] = np.arange(len(acc_sorted), dtype=np.uint32)
-    got = engine.run_consensus_host(t, tab.seg_off, tab.bit_score.astype(np.int32), tab.tax_row.astype(np.uint32),
+    got = engine.run_consensus_host(t, tab.seg_off, tab.bit_score.astype(np.int32), t.engine_rows(tab.tax_row.astype(np.uint32)),
                                     tab.pident, tab.align_len.astype(np.int32), acc_rank[tab.acc_idx], strategy=strategy)
     faithful = orc.run(tab, taxon="bacteria", strategy=strategy).results()
     for q, (exp, rec) in enumerate(zip(taxa, got)):

@@ -96,7 +96,13 @@ def test_taxid_lookup():
     tax = synth.make_taxonomy(300, 2)
     t = _host_tax(tax, "bacteria")
     rows = t.lookup(np.array([tax.taxid[5], 999999999, tax.taxid[299]], dtype=np.int64))
-    assert rows.tolist() == [5, N.BLU_UNMATCHED_TAXID, 299]
+    fwd, inv = t.row_map()
+    assert rows.tolist() == [int(fwd[5]), N.BLU_UNMATCHED_TAXID, int(fwd[299])]     # engine row ids
+    assert sorted(fwd.tolist()) == list(range(tax.n)) and (inv[fwd] == np.arange(tax.n)).all()
+    # engine row ids follow the lexicographic order of the lineages
+    lin = [tuple(tax.lin_node[int(tax.lin_off[i]):int(tax.lin_off[i + 1])]) for i in inv]
+    assert lin == sorted(lin)
+    assert t.engine_rows(np.array([5, -1, 299], dtype=np.int32)).tolist() == rows.tolist()
 
 
 def test_no_cpu_fallback():
