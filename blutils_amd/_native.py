@@ -15,6 +15,8 @@ EXPORTS = (
     "blu_taxonomy_rank_name", "blu_taxonomy_row_cutoffs", "blu_taxonomy_lookup", "blu_taxonomy_row_map", "blu_consensus_run",
     "blu_consensus_last_launch",
 )
+# include/blu_pipeline.h
+PIPELINE_EXPORTS = ("blu_build_consensus_identities", "blu_free_text", "blu_custom_taxon_from_file")
 
 BLU_UNMATCHED_TAXID = 0xFFFFFFFF
 BLU_NONE_U8, BLU_NONE_U16, BLU_MAR_NEVER_EQUAL = 0xFF, 0xFFFF, 0xFFFE

@@ -64,6 +64,8 @@ const char* consensus_kernel_name();
 void consensus_last_geometry(uint32_t* grid, uint32_t* block);
 
 void set_error(const char* fmt, ...);
+// LinnaeanRank::from_str (linnaean_ranks.rs:52-72): enum kind 0..8, or K_FIRST_OTHER with the slug in *other
+uint16_t parse_rank(const char* name, std::string* other);
 
 }  // namespace blu
 

@@ -1,0 +1,668 @@
+// Host-side drop-in for `build_consensus_identities` + the result writer
+// (include/blu_pipeline.h).  Reference files followed:
+//   core/src/use_cases/build_consensus_identities/mod.rs:40-129   orchestration, headers without hits
+//   mod.rs:134-221   fold_results_by_query: per-query rows in file order, quotes stripped, bit_score f64 -> i64
+//   mod.rs:226-244   outfmt-6 schema (13 tab-separated columns, no header)
+//   mod.rs:246-327   blutils DB JSON -> {taxid, numericLineage | textLineage}
+//   domain/dtos/blast_result.rs:38-120   lineage grammar `rank__identifier(;rank__identifier)*`
+//   domain/dtos/consensus_result.rs:47-88, build_blast_consensus_identity.rs:43-63   consensus beans
+//   use_cases/write_blutils_output.rs:87-111,126-232   flattening, sort by query, JSON / JSONL
+// Third-party edges not pinned by any reference test: polars' CSV number parsing (strtod/strtoll
+// here), serde_json's float printing (shortest round-trip digits here, ".0" appended to integral values).
+#include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <charconv>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "blu_internal.h"
+#include "blu_pipeline.h"
+
+using namespace blu;
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct MappedFile {
+    const char* data = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    bool open(const char* path) {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) return false;
+        size = (size_t)st.st_size;
+        if (size == 0) { data = ""; return true; }
+        void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (p == MAP_FAILED) return false;
+        data = (const char*)p;
+        return true;
+    }
+    ~MappedFile() {
+        if (data && size) munmap((void*)data, size);
+        if (fd >= 0) close(fd);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// minimal JSON reader (enough for the blutils DB and the custom-cutoff file)
+// ---------------------------------------------------------------------------------------------------------
+struct Json {
+    const char* p;
+    const char* end;
+    bool ok = true;
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+    bool eat(char c) { ws(); if (p < end && *p == c) { ++p; return true; } return false; }
+    bool peek(char c) { ws(); return p < end && *p == c; }
+    bool string(std::string* out) {
+        ws();
+        if (p >= end || *p != '"') { ok = false; return false; }
+        ++p;
+        if (out) out->clear();
+        while (p < end && *p != '"') {
+            if (*p == '\\' && p + 1 < end) {
+                ++p;
+                char c = *p++;
+                char r = c;
+                switch (c) {
+                    case 'n': r = '\n'; break; case 't': r = '\t'; break; case 'r': r = '\r'; break;
+                    case 'b': r = '\b'; break; case 'f': r = '\f'; break;
+                    case 'u': {
+                        unsigned v = 0;
+                        for (int i = 0; i < 4 && p < end; ++i, ++p) v = v * 16 + (unsigned)(isdigit((unsigned char)*p) ? *p - '0' : (tolower(*p) - 'a' + 10));
+                        if (out) {  // UTF-8 encode the BMP code point (surrogate pairs are not expected in lineages)
+                            if (v < 0x80) out->push_back((char)v);
+                            else if (v < 0x800) { out->push_back((char)(0xC0 | (v >> 6))); out->push_back((char)(0x80 | (v & 0x3F))); }
+                            else { out->push_back((char)(0xE0 | (v >> 12))); out->push_back((char)(0x80 | ((v >> 6) & 0x3F))); out->push_back((char)(0x80 | (v & 0x3F))); }
+                        }
+                        continue;
+                    }
+                    default: break;
+                }
+                if (out) out->push_back(r);
+            } else {
+                if (out) out->push_back(*p);
+                ++p;
+            }
+        }
+        if (p >= end) { ok = false; return false; }
+        ++p;
+        return true;
+    }
+    bool number(double* out) {
+        ws();
+        char* e = nullptr;
+        double v = strtod(p, &e);
+        if (e == p) { ok = false; return false; }
+        p = e;
+        if (out) *out = v;
+        return true;
+    }
+    void skip() {
+        ws();
+        if (p >= end) { ok = false; return; }
+        if (*p == '"') { string(nullptr); return; }
+        if (*p == '{') {
+            ++p;
+            if (eat('}')) return;
+            do { string(nullptr); if (!eat(':')) { ok = false; return; } skip(); } while (ok && eat(','));
+            if (!eat('}')) ok = false;
+            return;
+        }
+        if (*p == '[') {
+            ++p;
+            if (eat(']')) return;
+            do { skip(); } while (ok && eat(','));
+            if (!eat(']')) ok = false;
+            return;
+        }
+        while (p < end && *p != ',' && *p != '}' && *p != ']' && *p != ' ' && *p != '\n' && *p != '\r' && *p != '\t') ++p;  // number / literal
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// taxonomy side
+// ---------------------------------------------------------------------------------------------------------
+struct Db {
+    std::vector<int64_t> taxid;
+    std::vector<uint64_t> lin_off{0};
+    std::vector<uint32_t> lin_node;
+    std::vector<uint16_t> lin_rank;          // index into rank_raw
+    std::vector<uint8_t> bad;
+    std::vector<std::string> rank_raw;       // rank strings as they appear in lineages
+    std::vector<std::string> rank_display;   // canonical Display of rank_raw[i]
+    std::vector<std::string> node_ident;     // node id -> identifier string
+    std::unordered_map<std::string, uint16_t> rank_ids;
+    std::unordered_map<std::string, uint32_t> node_ids;   // key: Display(rank) + '\x1f' + identifier
+    std::unordered_map<int64_t, uint32_t> row_of;
+};
+
+std::string canonical_display(const std::string& raw) {
+    static const char* letters[9] = {"u", "d", "k", "p", "c", "o", "f", "g", "s"};
+    std::string other;
+    uint16_t k = parse_rank(raw.c_str(), &other);
+    return k < K_FIRST_OTHER ? std::string(letters[k]) : other;
+}
+
+// blast_result.rs:38-120: split on ';' then on "__", every element must give exactly two parts
+void add_lineage(Db& db, int64_t taxid, const std::string& lineage) {
+    const size_t first = db.lin_node.size();
+    bool bad = false;
+    size_t pos = 0;
+    for (;;) {
+        size_t semi = lineage.find(';', pos);
+        std::string_view el(lineage.data() + pos, (semi == std::string::npos ? lineage.size() : semi) - pos);
+        size_t sep = el.find("__");
+        if (sep == std::string_view::npos || el.find("__", sep + 2) != std::string_view::npos) bad = true;   // != 2 parts
+        if (!bad) {
+            std::string rank(el.substr(0, sep)), ident(el.substr(sep + 2));
+            auto rit = db.rank_ids.find(rank);
+            if (rit == db.rank_ids.end()) {
+                rit = db.rank_ids.emplace(rank, (uint16_t)db.rank_raw.size()).first;
+                db.rank_raw.push_back(rank);
+                db.rank_display.push_back(canonical_display(rank));
+            }
+            std::string key = db.rank_display[rit->second];
+            key.push_back('\x1f');
+            key += ident;
+            auto nit = db.node_ids.find(key);
+            if (nit == db.node_ids.end()) {
+                nit = db.node_ids.emplace(std::move(key), (uint32_t)db.node_ident.size()).first;
+                db.node_ident.push_back(ident);
+            }
+            db.lin_node.push_back(nit->second);
+            db.lin_rank.push_back(rit->second);
+        }
+        if (semi == std::string::npos) break;
+        pos = semi + 1;
+    }
+    if (bad) { db.lin_node.resize(first); db.lin_rank.resize(first); }
+    db.bad.push_back(bad ? 1 : 0);
+    db.row_of.emplace(taxid, (uint32_t)db.taxid.size());   // first row wins for a duplicated taxid
+    db.taxid.push_back(taxid);
+    db.lin_off.push_back(db.lin_node.size());
+}
+
+// mod.rs:246-327 + domain/dtos/taxonomies_map.rs:6-32
+int load_db(const char* path, bool use_taxid, Db& db) {
+    MappedFile f;
+    if (!f.open(path)) { set_error("Taxonomies file not found: %s", path); return BLU_ERR_IO; }
+    Json j{f.data, f.data + f.size};
+    if (!j.eat('{')) { set_error("taxonomies file is not a JSON object"); return BLU_ERR_PARSE; }
+    bool found = false;
+    std::string key, numeric, text;
+    if (!j.peek('}')) {
+        do {
+            if (!j.string(&key) || !j.eat(':')) { j.ok = false; break; }
+            if (key != "taxonomies") { j.skip(); continue; }
+            found = true;
+            if (!j.eat('[')) { j.ok = false; break; }
+            if (j.eat(']')) continue;
+            do {
+                if (!j.eat('{')) { j.ok = false; break; }
+                double taxid = 0;
+                bool has_taxid = false, has_n = false, has_t = false;
+                if (!j.peek('}')) {
+                    do {
+                        if (!j.string(&key) || !j.eat(':')) { j.ok = false; break; }
+                        if (key == "taxid") has_taxid = j.number(&taxid);
+                        else if (key == "numericLineage") has_n = j.string(&numeric);
+                        else if (key == "textLineage") has_t = j.string(&text);
+                        else j.skip();
+                    } while (j.ok && j.eat(','));
+                }
+                if (!j.eat('}')) j.ok = false;
+                if (!j.ok) break;
+                if (!has_taxid || !has_n || !has_t) { set_error("taxonomy entry %zu lacks taxid/numericLineage/textLineage", db.taxid.size()); return BLU_ERR_PARSE; }
+                add_lineage(db, (int64_t)taxid, use_taxid ? numeric : text);   // mod.rs:278 (u64 -> f64 -> i64), :287-291
+            } while (j.ok && j.eat(','));
+            if (!j.eat(']')) j.ok = false;
+        } while (j.ok && j.eat(','));
+    }
+    if (!j.ok || !found) { set_error("Unexpected error detected on parse `taxonomies` as json (offset %zu)", (size_t)(j.p - f.data)); return BLU_ERR_PARSE; }
+    return BLU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// hit table side
+// ---------------------------------------------------------------------------------------------------------
+struct HitTable {
+    std::vector<std::string> query_names;        // first-appearance order
+    std::vector<uint64_t> seg_off;
+    std::vector<int32_t> bitscore, align_len;
+    std::vector<uint32_t> tax_desc_row, acc_rank, acc_id;
+    std::vector<double> pident;
+    std::vector<std::string> accessions;         // by acc_id
+    uint64_t unmatched = 0;
+};
+
+std::string strip_quotes(std::string_view v) {   // mod.rs:169-172 `.replace("\"", "")`
+    std::string s;
+    s.reserve(v.size());
+    for (char c : v) if (c != '"') s.push_back(c);
+    return s;
+}
+
+int load_hits(const char* path, const Db& db, HitTable& ht) {
+    MappedFile f;
+    if (!f.open(path)) { set_error("Unexpected error occurred on load table: %s", path); return BLU_ERR_IO; }
+    struct Row { uint32_t q, acc, tax; int32_t bs, aln; double pid; };
+    std::vector<Row> rows;
+    std::unordered_map<std::string, uint32_t> qids, accids;
+    std::vector<uint32_t> per_query;
+    const char* p = f.data;
+    const char* end = f.data + f.size;
+    uint64_t line_no = 0;
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        const char* lend = le;
+        if (lend > p && lend[-1] == '\r') --lend;
+        ++line_no;
+        if (lend > p) {
+            std::string_view col[13];
+            int nc = 0;
+            const char* c = p;
+            while (nc < 13) {
+                const char* tab = (const char*)memchr(c, '\t', (size_t)(lend - c));
+                const char* ce = tab ? tab : lend;
+                col[nc++] = std::string_view(c, (size_t)(ce - c));
+                if (!tab) break;
+                c = tab + 1;
+            }
+            if (nc < 13) { set_error("line %llu of %s has %d columns, outfmt-6 with 13 expected (mod.rs:226-244)", (unsigned long long)line_no, path, nc); return BLU_ERR_PARSE; }
+            auto num = [&](std::string_view v, double* out) {
+                std::string tmp(v);
+                char* e = nullptr;
+                *out = strtod(tmp.c_str(), &e);
+                return e != tmp.c_str();
+            };
+            double taxid_f, pid, aln, bs;
+            if (!num(col[2], &taxid_f) || !num(col[3], &pid) || !num(col[4], &aln) || !num(col[12], &bs)) {
+                set_error("line %llu of %s: numeric column does not parse", (unsigned long long)line_no, path); return BLU_ERR_PARSE;
+            }
+            const double bs_t = std::trunc(bs);               // mod.rs:184 AnyValue::Float64 -> try_extract::<i64>
+            if (!(bs_t >= -2147483648.0 && bs_t <= 2147483647.0) || !(aln >= -2147483648.0 && aln <= 2147483647.0)) {
+                set_error("line %llu of %s: bit_score / align_length outside the 32-bit range of the engine columns", (unsigned long long)line_no, path); return BLU_ERR_PARSE;
+            }
+            Row r;
+            std::string q = strip_quotes(col[0]), a = strip_quotes(col[1]);
+            auto qi = qids.find(q);
+            if (qi == qids.end()) { qi = qids.emplace(q, (uint32_t)ht.query_names.size()).first; ht.query_names.push_back(q); per_query.push_back(0); }
+            auto ai = accids.find(a);
+            if (ai == accids.end()) { ai = accids.emplace(a, (uint32_t)ht.accessions.size()).first; ht.accessions.push_back(a); }
+            r.q = qi->second; r.acc = ai->second;
+            auto ti = db.row_of.find((int64_t)taxid_f);
+            r.tax = ti == db.row_of.end() ? BLU_UNMATCHED_TAXID : ti->second;    // left join (mod.rs:72-76)
+            if (r.tax == BLU_UNMATCHED_TAXID) ++ht.unmatched;
+            r.bs = (int32_t)bs_t; r.aln = (int32_t)aln; r.pid = pid;
+            rows.push_back(r);
+            ++per_query[r.q];
+        }
+        p = nl ? nl + 1 : end;
+    }
+    // order-preserving accession ranks (String::cmp is bytewise)
+    std::vector<uint32_t> by_name(ht.accessions.size());
+    for (uint32_t i = 0; i < by_name.size(); ++i) by_name[i] = i;
+    std::sort(by_name.begin(), by_name.end(), [&](uint32_t a, uint32_t b) { return ht.accessions[a] < ht.accessions[b]; });
+    std::vector<uint32_t> rank_of(by_name.size());
+    for (uint32_t i = 0; i < by_name.size(); ++i) rank_of[by_name[i]] = i;
+    // stable grouping: queries in first-appearance order, rows of a query in file order (mod.rs:192-208)
+    const size_t nq = ht.query_names.size(), nh = rows.size();
+    ht.seg_off.assign(nq + 1, 0);
+    for (size_t q = 0; q < nq; ++q) ht.seg_off[q + 1] = ht.seg_off[q] + per_query[q];
+    std::vector<uint64_t> cur(ht.seg_off.begin(), ht.seg_off.end() - 1);
+    ht.bitscore.resize(nh); ht.align_len.resize(nh); ht.tax_desc_row.resize(nh); ht.acc_rank.resize(nh); ht.acc_id.resize(nh); ht.pident.resize(nh);
+    for (const Row& r : rows) {
+        const uint64_t i = cur[r.q]++;
+        ht.bitscore[i] = r.bs; ht.align_len[i] = r.aln; ht.tax_desc_row[i] = r.tax; ht.acc_rank[i] = rank_of[r.acc];
+        ht.acc_id[i] = r.acc; ht.pident[i] = r.pid;
+    }
+    return BLU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rendering
+// ---------------------------------------------------------------------------------------------------------
+void json_str(std::string& o, const std::string& s) {
+    o.push_back('"');
+    for (unsigned char c : s) {
+        switch (c) {
+            case '"': o += "\\\""; break; case '\\': o += "\\\\"; break; case '\n': o += "\\n"; break;
+            case '\r': o += "\\r"; break; case '\t': o += "\\t"; break; case '\b': o += "\\b"; break; case '\f': o += "\\f"; break;
+            default:
+                if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+                else o.push_back((char)c);
+        }
+    }
+    o.push_back('"');
+}
+void json_f64(std::string& o, double v) {   // serde_json: shortest digits that round-trip, integral values keep ".0"
+    if (!std::isfinite(v)) { o += "null"; return; }
+    char b[64];
+    auto r = std::to_chars(b, b + sizeof b, v);
+    std::string s(b, r.ptr);
+    if (s.find_first_of(".eE") == std::string::npos) s += ".0";
+    o += s;
+}
+
+struct Renderer {
+    const Db& db;
+    const HitTable& ht;
+    const blu_taxonomy* tax;
+    std::string lineage_string(uint32_t desc_row) const {   // taxonomy_beans_to_string (taxonomy_bean.rs:38-45)
+        std::string s;
+        for (uint64_t i = db.lin_off[desc_row]; i < db.lin_off[desc_row + 1]; ++i) {
+            if (i > db.lin_off[desc_row]) s.push_back(';');
+            s += db.rank_display[db.lin_rank[i]]; s += "__"; s += db.node_ident[db.lin_node[i]];
+        }
+        return s;
+    }
+    std::string rank_serde_of(uint32_t desc_row, uint32_t level) const {
+        uint16_t codes[BLU_MAX_DEPTH];
+        blu_taxonomy_row_cutoffs(tax, desc_row, BLU_MAX_DEPTH, nullptr, nullptr, codes);
+        return blu_taxonomy_rank_name(tax, codes[level], 1);
+    }
+    struct Bean { std::string rank_serde, identifier, taxonomy; int32_t occurrences = 0; std::vector<std::string> accessions; uint32_t node; };
+
+    // pretty = serde_json::to_string_pretty layout (2-space indent); ind = indentation of the object's own line
+    void taxon(std::string& o, uint64_t q, const blu_result& r, bool pretty, int ind) const {
+        auto nl = [&](int extra) { if (pretty) { o.push_back('\n'); o.append((size_t)(ind + extra) * 2, ' '); } };
+        const char* colon = pretty ? ": " : ":";
+        const uint32_t row = r.ref_row, drow = ht.tax_desc_row[row];
+        const uint64_t lo = db.lin_off[drow];
+        const uint32_t len = (uint32_t)(db.lin_off[drow + 1] - lo);
+        std::string taxonomy;
+        for (uint32_t jl = 0; jl < len; ++jl)
+            if ((r.level_mask >> jl) & 1) {
+                if (!taxonomy.empty()) taxonomy.push_back(';');
+                taxonomy += db.rank_display[db.lin_rank[lo + jl]]; taxonomy += "__"; taxonomy += db.node_ident[db.lin_node[lo + jl]];
+            }
+        // consensus beans
+        std::vector<Bean> beans;
+        const bool single = r.status == BLU_ST_CONSENSUS_SINGLE;
+        if (single) {   // find_single_query_consensus.rs:123-145
+            Bean b;
+            b.rank_serde = blu_taxonomy_rank_name(tax, r.reached_rank, 1);
+            b.identifier = db.node_ident[r.identifier_node];
+            b.occurrences = 1;
+            b.taxonomy = lineage_string(drow);
+            b.accessions.push_back(ht.accessions[ht.acc_id[row]]);
+            beans.push_back(std::move(b));
+        } else {
+            const int32_t M = ht.bitscore[row];
+            std::vector<uint32_t> S;
+            for (uint64_t i = ht.seg_off[q]; i < ht.seg_off[q + 1]; ++i) if (ht.bitscore[i] == M) S.push_back((uint32_t)i);
+            auto len_of = [&](uint32_t i) { const uint32_t d = ht.tax_desc_row[i]; return (uint32_t)(db.lin_off[d + 1] - db.lin_off[d]); };
+            std::stable_sort(S.begin(), S.end(), [&](uint32_t a, uint32_t b) {   // find_multi_taxa_consensus.rs:39-54
+                const uint32_t la = len_of(a), lb = len_of(b);
+                if (la != lb) return la < lb;
+                if (ht.pident[a] < ht.pident[b]) return true;
+                if (ht.pident[a] > ht.pident[b]) return false;
+                if (ht.align_len[a] != ht.align_len[b]) return ht.align_len[a] < ht.align_len[b];
+                return ht.acc_rank[a] < ht.acc_rank[b];
+            });
+            const uint32_t lvl = (r.flags & BLU_FLAG_AGREE) ? r.bean_index : (uint32_t)r.bean_index + 1;   // level the scan stopped at
+            for (uint32_t i : S) {   // consensus_result.rs:65-88 fold, first-seen order
+                const uint32_t d = ht.tax_desc_row[i];
+                const uint32_t node = db.lin_node[db.lin_off[d] + lvl];
+                Bean* slot = nullptr;
+                for (Bean& b : beans) if (b.node == node) { slot = &b; break; }
+                if (!slot) {
+                    Bean b;
+                    b.node = node;
+                    b.rank_serde = rank_serde_of(d, lvl);
+                    b.identifier = db.node_ident[node];
+                    b.taxonomy = lineage_string(d);
+                    beans.push_back(std::move(b));
+                    slot = &beans.back();
+                }
+                const std::string& acc = ht.accessions[ht.acc_id[i]];
+                if (slot->accessions.empty() || slot->accessions.back() != acc) slot->accessions.push_back(acc);   // extend + dedup()
+                slot->occurrences += 1;
+            }
+            std::stable_sort(beans.begin(), beans.end(), [](const Bean& a, const Bean& b) {   // build_blast_consensus_identity.rs:49-60
+                if (a.occurrences != b.occurrences) return a.occurrences > b.occurrences;
+                return a.identifier < b.identifier;
+            });
+        }
+        o.push_back('{');
+        nl(1); o += "\"reachedRank\""; o += colon; json_str(o, blu_taxonomy_rank_name(tax, r.reached_rank, 1));
+        o.push_back(','); nl(1); o += "\"maxAllowedRank\""; o += colon;
+        if (r.max_allowed_level == BLU_NONE_U8) o += "null";
+        else {
+            uint8_t isdef[BLU_MAX_DEPTH]; uint16_t codes[BLU_MAX_DEPTH];
+            blu_taxonomy_row_cutoffs(tax, drow, BLU_MAX_DEPTH, nullptr, isdef, codes);
+            // DefaultRank(rank) -> rank (serde name); NonDefaultRank(name) -> Other(name) (build_blast_consensus_identity.rs:22-30)
+            json_str(o, blu_taxonomy_rank_name(tax, codes[r.max_allowed_level], isdef[r.max_allowed_level] ? 1 : 0));
+        }
+        o.push_back(','); nl(1); o += "\"identifier\""; o += colon; json_str(o, db.node_ident[r.identifier_node]);
+        o.push_back(','); nl(1); o += "\"percIdentity\""; o += colon; json_f64(o, ht.pident[row]);
+        o.push_back(','); nl(1); o += "\"bitScore\""; o += colon; json_f64(o, (double)ht.bitscore[row]);
+        o.push_back(','); nl(1); o += "\"taxonomy\""; o += colon; json_str(o, taxonomy);
+        o.push_back(','); nl(1); o += "\"mutated\""; o += colon; o += (r.flags & BLU_FLAG_MUTATED) ? "true" : "false";
+        o.push_back(','); nl(1); o += "\"singleMatch\""; o += colon; o += single ? "true" : "false";
+        o.push_back(','); nl(1); o += "\"consensusBeans\""; o += colon; o.push_back('[');
+        for (size_t bi = 0; bi < beans.size(); ++bi) {
+            const Bean& b = beans[bi];
+            if (bi) o.push_back(',');
+            nl(2); o.push_back('{');
+            nl(3); o += "\"rank\""; o += colon; json_str(o, b.rank_serde);
+            o.push_back(','); nl(3); o += "\"identifier\""; o += colon; json_str(o, b.identifier);
+            o.push_back(','); nl(3); o += "\"occurrences\""; o += colon; o += std::to_string(b.occurrences);
+            o.push_back(','); nl(3); o += "\"taxonomy\""; o += colon; json_str(o, b.taxonomy);
+            o.push_back(','); nl(3); o += "\"accessions\""; o += colon; o.push_back('[');
+            for (size_t k = 0; k < b.accessions.size(); ++k) { if (k) o.push_back(','); nl(4); json_str(o, b.accessions[k]); }
+            if (!b.accessions.empty()) nl(3);
+            o.push_back(']');
+            nl(2); o.push_back('}');
+        }
+        if (!beans.empty()) nl(1);
+        o.push_back(']');
+        nl(0); o.push_back('}');
+    }
+};
+
+std::string uuid_v4() {
+    unsigned char b[16];
+    FILE* f = fopen("/dev/urandom", "rb");
+    if (!f || fread(b, 1, 16, f) != 16) for (auto& x : b) x = (unsigned char)rand();
+    if (f) fclose(f);
+    b[6] = (unsigned char)((b[6] & 0x0F) | 0x40);
+    b[8] = (unsigned char)((b[8] & 0x3F) | 0x80);
+    char s[40];
+    snprintf(s, sizeof s, "%02x%02x%02x%02x-%02x%02x-%02x%02x-%02x%02x-%02x%02x%02x%02x%02x%02x", b[0], b[1], b[2], b[3], b[4], b[5],
+             b[6], b[7], b[8], b[9], b[10], b[11], b[12], b[13], b[14], b[15]);
+    return s;
+}
+
+const char* status_site(uint8_t st) {
+    switch (st) {
+        case BLU_ST_ERR_UNMATCHED_TAXID: return "taxid of a top-score hit is not in the taxonomies file: lineage `null` fails parse_taxonomy (find_single_query_consensus.rs:58-60)";
+        case BLU_ST_ERR_BAD_LINEAGE: return "lineage of a top-score hit fails parse_taxonomy (blast_result.rs:109-114)";
+        case BLU_ST_ERR_ROOT_DISAGREE: return "top-score hits disagree at the first lineage level: `index - 1` underflow (find_multi_taxa_consensus.rs:181)";
+        case BLU_ST_ERR_SINGLE_BELOW_CUTOFFS: return "single top-score hit below every identity cutoff (find_single_query_consensus.rs:113-119)";
+        case BLU_ST_ERR_BAD_PIDENT: return "NaN perc_identity among the top-score hits";
+        default: return "unknown";
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int blu_build_consensus_identities(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
+                                   const char* taxonomies_file, const blu_pipeline_params* params, char** out_text,
+                                   size_t* out_len, blu_pipeline_stats* stats) {
+    if (!blast_output_file || !taxonomies_file || !params || !out_text) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    *out_text = nullptr;
+    if (out_len) *out_len = 0;
+    if (params->out_format == BLU_OUT_YAML) { set_error("YAML output is not implemented yet (JSON and JSONL are)"); return BLU_ERR_INVALID_ARG; }
+    blu_pipeline_stats st{};
+    double t0 = now_s();
+    Db db;
+    int rc = load_db(taxonomies_file, params->use_taxid != 0, db);     // mod.rs:64
+    if (rc != BLU_OK) return rc;
+    st.t_load_db_s = now_s() - t0;
+    t0 = now_s();
+    HitTable ht;
+    rc = load_hits(blast_output_file, db, ht);                         // mod.rs:54, 72-82
+    if (rc != BLU_OK) return rc;
+    st.t_load_hits_s = now_s() - t0;
+    st.n_hits = ht.bitscore.size(); st.n_queries = ht.query_names.size(); st.n_taxids = db.taxid.size(); st.n_unmatched_rows = ht.unmatched;
+
+    t0 = now_s();
+    std::vector<const char*> names;
+    for (auto& s : db.rank_raw) names.push_back(s.c_str());
+    blu_taxonomy_desc desc{};
+    desc.n_tax = db.taxid.size();
+    desc.taxid = db.taxid.data();
+    desc.lin_off = db.lin_off.data();
+    desc.lin_node = db.lin_node.data();
+    desc.lin_rank = db.lin_rank.data();
+    desc.n_ranks = (uint32_t)names.size();
+    desc.rank_names = names.data();
+    desc.bad = db.bad.data();
+    blu_taxonomy* tax = nullptr;
+    rc = blu_taxonomy_create(&desc, &params->cutoffs, params->device, &tax);
+    if (rc != BLU_OK) return rc;
+    std::vector<uint32_t> fwd(std::max<size_t>(db.taxid.size(), 1));
+    blu_taxonomy_row_map(tax, fwd.data(), nullptr);
+    std::vector<uint32_t> eng_rows(ht.tax_desc_row.size());
+    for (size_t i = 0; i < eng_rows.size(); ++i)
+        eng_rows[i] = ht.tax_desc_row[i] == BLU_UNMATCHED_TAXID ? BLU_UNMATCHED_TAXID : fwd[ht.tax_desc_row[i]];
+    std::vector<blu_result> recs(ht.query_names.size());
+    if (!recs.empty()) {
+        blu_hits h{};
+        h.bitscore = ht.bitscore.data(); h.tax_row = eng_rows.data(); h.pident = ht.pident.data();
+        h.align_len = ht.align_len.data(); h.acc_rank = ht.acc_rank.data(); h.seg_off = ht.seg_off.data();
+        h.n_hits = ht.bitscore.size(); h.n_queries = ht.query_names.size(); h.on_device = 0;
+        blu_run_params rp{params->strategy, 0, nullptr};
+        rc = blu_consensus_run(tax, &h, &rp, recs.data());             // mod.rs:104-128
+        if (rc != BLU_OK) { blu_taxonomy_destroy(tax); return rc; }
+    }
+    st.t_engine_s = now_s() - t0;
+
+    t0 = now_s();
+    // results + headers without hits (mod.rs:86-102), sorted by query (write_blutils_output.rs:111)
+    struct Item { const std::string* name; int64_t q; };
+    std::vector<Item> items;
+    for (size_t q = 0; q < ht.query_names.size(); ++q) items.push_back({&ht.query_names[q], (int64_t)q});
+    std::vector<std::string> extra;
+    if (headers) {
+        std::unordered_map<std::string, uint32_t> have;
+        for (size_t q = 0; q < ht.query_names.size(); ++q) have.emplace(ht.query_names[q], (uint32_t)q);
+        extra.reserve(n_headers);
+        for (uint64_t i = 0; i < n_headers; ++i)
+            if (!have.count(headers[i])) extra.emplace_back(headers[i]);
+        for (auto& s : extra) items.push_back({&s, -1});
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return *a.name < *b.name; });
+    for (const Item& it : items) {
+        if (it.q < 0) continue;
+        const uint8_t s = recs[(size_t)it.q].status;
+        if (s >= 16 && !params->lenient) {
+            set_error("query `%s`: %s", it.name->c_str(), status_site(s));
+            blu_taxonomy_destroy(tax);
+            return BLU_ERR_REFERENCE_PANIC;
+        }
+    }
+    const bool pretty = params->out_format == BLU_OUT_JSON;
+    const std::string run_id = uuid_v4();
+    Renderer R{db, ht, tax};
+    std::string o;
+    o.reserve(items.size() * 512);
+    if (pretty) o += "{\n  \"results\": [";
+    else o += "null\n";                                               // JSONL: the (absent) config line comes first
+    bool first = true;
+    for (const Item& it : items) {
+        const int ind = pretty ? 2 : 0;
+        auto nl = [&](int extra) { if (pretty) { o.push_back('\n'); o.append((size_t)(ind + extra) * 2, ' '); } };
+        const char* colon = pretty ? ": " : ":";
+        if (pretty) { if (!first) o.push_back(','); nl(0); }
+        first = false;
+        o.push_back('{');
+        nl(1); o += "\"runId\""; o += colon; json_str(o, run_id);
+        o.push_back(','); nl(1); o += "\"query\""; o += colon; json_str(o, *it.name);
+        o.push_back(','); nl(1); o += "\"taxon\""; o += colon;
+        if (it.q < 0 || recs[(size_t)it.q].status >= 2) o += "null";
+        else R.taxon(o, (uint64_t)it.q, recs[(size_t)it.q], pretty, ind + 1);
+        nl(0); o.push_back('}');
+        if (!pretty) o.push_back('\n');
+    }
+    if (pretty) { if (!items.empty()) o += "\n  "; o += "],\n  \"config\": null\n}"; }
+    st.t_render_s = now_s() - t0;
+    blu_taxonomy_destroy(tax);
+    char* buf = (char*)malloc(o.size() + 1);
+    if (!buf) { set_error("out of memory"); return BLU_ERR_ALLOC; }
+    memcpy(buf, o.data(), o.size());
+    buf[o.size()] = 0;
+    *out_text = buf;
+    if (out_len) *out_len = o.size();
+    if (stats) *stats = st;
+    return BLU_OK;
+}
+
+void blu_free_text(char* text) { free(text); }
+
+// domain/dtos/taxon.rs:28-66: YAML (flat `key: value` lines) or JSON object with the eight fields
+int blu_custom_taxon_from_file(const char* path, blu_cutoff_config* cfg) {
+    if (!path || !cfg) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    const char* dot = strrchr(path, '.');
+    if (!dot || (strcmp(dot, ".yaml") != 0 && strcmp(dot, ".json") != 0)) { set_error("Custom taxon file must be a YAML or JSON file"); return BLU_ERR_INVALID_ARG; }
+    MappedFile f;
+    if (!f.open(path)) { set_error("Could not open custom taxon file: %s", path); return BLU_ERR_IO; }
+    static const char* fields[8] = {"domain", "kingdom", "phylum", "class", "order", "family", "genus", "species"};
+    memset(cfg, 0, sizeof *cfg);
+    cfg->taxon = BLU_TAXON_CUSTOM;
+    cfg->has_custom = 1;
+    auto set = [&](const std::string& k, double v) { for (int i = 0; i < 8; ++i) if (k == fields[i]) { cfg->custom[i] = (int16_t)v; cfg->custom_has[i] = 1; } };
+    if (strcmp(dot, ".json") == 0) {
+        Json j{f.data, f.data + f.size};
+        std::string key;
+        if (!j.eat('{')) { set_error("Could not parse custom taxon file from JSON"); return BLU_ERR_PARSE; }
+        if (!j.peek('}')) do {
+            double v;
+            if (!j.string(&key) || !j.eat(':')) { j.ok = false; break; }
+            if (j.peek('n')) { j.skip(); continue; }
+            if (!j.number(&v)) break;
+            set(key, v);
+        } while (j.ok && j.eat(','));
+        if (!j.ok) { set_error("Could not parse custom taxon file from JSON"); return BLU_ERR_PARSE; }
+    } else {
+        std::string text(f.data, f.size);
+        size_t pos = 0;
+        while (pos < text.size()) {
+            size_t nl = text.find('\n', pos);
+            std::string line = text.substr(pos, nl == std::string::npos ? std::string::npos : nl - pos);
+            pos = nl == std::string::npos ? text.size() : nl + 1;
+            size_t hash = line.find('#');
+            if (hash != std::string::npos) line.resize(hash);
+            size_t colon = line.find(':');
+            if (colon == std::string::npos) continue;
+            std::string k = line.substr(0, colon), v = line.substr(colon + 1);
+            auto trim = [](std::string& s) { size_t a = s.find_first_not_of(" \t\r"), b = s.find_last_not_of(" \t\r"); s = a == std::string::npos ? "" : s.substr(a, b - a + 1); };
+            trim(k); trim(v);
+            if (v.empty() || v == "null" || v == "~") continue;
+            set(k, atof(v.c_str()));
+        }
+    }
+    if (!cfg->custom_has[0] || !cfg->custom_has[7]) { set_error("custom taxon file lacks the mandatory `domain`/`species` fields (taxon.rs:16-25)"); return BLU_ERR_PARSE; }
+    return BLU_OK;
+}
+
+}  // extern "C"

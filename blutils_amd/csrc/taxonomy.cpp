@@ -54,7 +54,7 @@ static std::string slugify_ascii(const std::string& s) {
 // linnaean_ranks.rs:52-72: lowercase + trim, letters and full names map to the
 // enum, anything else to Other(slugify(x)).  Returns the enum kind (0..8) or
 // K_FIRST_OTHER with `other` set.
-static uint16_t parse_rank(const char* name, std::string* other) {
+uint16_t parse_rank(const char* name, std::string* other) {
     std::string low;
     for (const unsigned char* p = (const unsigned char*)name; *p; ++p)
         low.push_back((*p >= 'A' && *p <= 'Z') ? (char)(*p + 32) : (char)*p);

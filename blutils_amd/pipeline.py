@@ -1,0 +1,93 @@
+"""ctypes front end of the host pipeline (include/blu_pipeline.h): the drop-in for the reference use-case
+
+    build_consensus_identities(blast_output, taxonomies_file, taxon, strategy, use_taxid, custom_taxon_values)
+    (core/src/use_cases/build_consensus_identities/mod.rs:40-47)  +  write_blutils_output (write_blutils_output.rs:33)
+
+Same argument names and meaning; the consensus itself runs on the GPU (no CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from typing import Optional, Sequence
+
+from . import _native as N
+
+OUT_FORMAT = {"json": 0, "jsonl": 1, "yaml": 2}
+BLU_ERR_REFERENCE_PANIC = 9
+
+
+class PipelineParams(C.Structure):
+    _fields_ = [("cutoffs", N.CutoffConfig), ("strategy", C.c_int32), ("use_taxid", C.c_int32), ("device", C.c_int32),
+                ("out_format", C.c_int32), ("lenient", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PipelineStats(C.Structure):
+    _fields_ = [("n_hits", C.c_uint64), ("n_queries", C.c_uint64), ("n_taxids", C.c_uint64),
+                ("n_unmatched_rows", C.c_uint64), ("t_load_db_s", C.c_double), ("t_load_hits_s", C.c_double),
+                ("t_engine_s", C.c_double), ("t_render_s", C.c_double)]
+
+
+def _bind():
+    L = N.lib()
+    L.blu_build_consensus_identities.restype = C.c_int
+    L.blu_build_consensus_identities.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_char_p, C.POINTER(PipelineParams),
+                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(PipelineStats)]
+    L.blu_free_text.argtypes = [C.c_void_p]
+    L.blu_custom_taxon_from_file.restype = C.c_int
+    L.blu_custom_taxon_from_file.argtypes = [C.c_char_p, C.POINTER(N.CutoffConfig)]
+    return L
+
+
+def custom_taxon_from_file(path: str) -> dict:
+    """CustomTaxon::from_file (domain/dtos/taxon.rs:28-66)."""
+    cfg = N.CutoffConfig()
+    rc = _bind().blu_custom_taxon_from_file(path.encode(), C.byref(cfg))
+    if rc != N.BLU_OK:
+        raise N.BluError(rc, "blu_custom_taxon_from_file")
+    return {k: int(cfg.custom[i]) for i, k in enumerate(N.CUSTOM_FIELDS) if cfg.custom_has[i]}
+
+
+def build_consensus_identities(blast_output: str, taxonomies_file: str, taxon: str = "bacteria",
+                               strategy: str = "relaxed", use_taxid: Optional[bool] = None,
+                               custom_taxon_values: Optional[dict] = None, headers: Optional[Sequence[str]] = None,
+                               out_format: str = "json", device: int = 0, lenient: bool = False, parse: bool = True):
+    """Returns (results, stats).  results: the parsed `results` list (json) / list of records (jsonl), sorted by
+    query, or the raw text when parse=False."""
+    L = _bind()
+    p = PipelineParams()
+    p.cutoffs.taxon = N.TAXON[taxon]
+    p.cutoffs.has_custom = 1 if custom_taxon_values is not None else 0
+    if custom_taxon_values is not None:
+        for i, k in enumerate(N.CUSTOM_FIELDS):
+            if custom_taxon_values.get(k) is not None:
+                p.cutoffs.custom[i] = int(custom_taxon_values[k])
+                p.cutoffs.custom_has[i] = 1
+    p.strategy = N.STRATEGY[strategy]
+    p.use_taxid = 1 if use_taxid else 0
+    p.device = device
+    p.out_format = OUT_FORMAT[out_format]
+    p.lenient = 1 if lenient else 0
+    hdr_arr, n_hdr = None, 0
+    if headers is not None:
+        enc = [h.encode() for h in headers]
+        hdr_arr = (C.c_char_p * max(1, len(enc)))(*enc)
+        n_hdr = len(enc)
+    text, n = C.c_void_p(), C.c_size_t()
+    st = PipelineStats()
+    rc = L.blu_build_consensus_identities(blast_output.encode(), C.cast(hdr_arr, C.c_void_p) if hdr_arr else None, n_hdr,
+                                          taxonomies_file.encode(), C.byref(p), C.byref(text), C.byref(n), C.byref(st))
+    if rc != N.BLU_OK:
+        raise N.BluError(rc, "blu_build_consensus_identities")
+    try:
+        raw = C.string_at(text, n.value).decode("utf-8")
+    finally:
+        L.blu_free_text(text)
+    stats = {f: getattr(st, f) for f, _ in PipelineStats._fields_}
+    if not parse:
+        return raw, stats
+    if out_format == "json":
+        return json.loads(raw)["results"], stats
+    lines = raw.splitlines()
+    assert lines[0] == "null"   # the (absent) config line (write_blutils_output.rs:169-175)
+    return [json.loads(l) for l in lines[1:]], stats

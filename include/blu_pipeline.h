@@ -1,0 +1,68 @@
+/*
+ * blu_pipeline.h — host-side drop-in for blutils' `build_consensus_identities`
+ * use-case and the result writer behind `blu blastn build-consensus`.
+ *
+ * Reference entry points mirrored (same arguments, same meaning):
+ *   core/src/use_cases/build_consensus_identities/mod.rs:40-47
+ *     build_consensus_identities(blast_output: ParallelBlastOutput{output_file, headers},
+ *                                taxonomies_file, taxon, strategy, use_taxid, custom_taxon_values)
+ *   core/src/use_cases/write_blutils_output.rs:33-38
+ *     write_blutils_output(results, config, blutils_out_file, out_format)
+ *
+ * What runs where: text ingest (outfmt-6 TSV, blutils DB JSON), lineage
+ * interning, the taxid join and the per-query grouping are host C++; the
+ * per-query consensus itself is the HIP engine (blu_consensus_run); strings and
+ * consensus beans are rebuilt on the host from the 32-byte records.
+ */
+#ifndef BLU_PIPELINE_H
+#define BLU_PIPELINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "blu_consensus.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* write_blutils_output.rs:20-31 OutputFormat */
+enum blu_out_format { BLU_OUT_JSON = 0, BLU_OUT_JSONL = 1, BLU_OUT_YAML = 2 };
+
+typedef struct blu_pipeline_params {
+    blu_cutoff_config cutoffs;   /* taxon + Option<CustomTaxon> */
+    int32_t strategy;            /* enum blu_strategy */
+    int32_t use_taxid;           /* Option<bool>: != 0 -> numericLineage, else textLineage (mod.rs:287-291) */
+    int32_t device;              /* HIP device ordinal */
+    int32_t out_format;          /* enum blu_out_format */
+    int32_t lenient;             /* 0: a query that makes the reference panic fails the call (BLU_ERR_REFERENCE_PANIC),
+                                    like the reference aborts; 1: such queries are written with "taxon": null */
+    int32_t reserved;
+} blu_pipeline_params;
+
+#define BLU_ERR_REFERENCE_PANIC 9 /* a per-query condition on which the reference panics (see blu_status >= 16) */
+
+typedef struct blu_pipeline_stats {
+    uint64_t n_hits, n_queries, n_taxids, n_unmatched_rows;
+    double t_load_db_s, t_load_hits_s, t_engine_s, t_render_s;
+} blu_pipeline_stats;
+
+/* Runs the whole use-case.  headers/n_headers: Option<Vec<String>> of FASTA ids (NULL/0 = None): ids without a
+ * hit row become NoConsensusFound entries (mod.rs:86-102).  On success *out_text is a malloc'd buffer with the
+ * serialized results, sorted by query (write_blutils_output.rs:111), in `out_format`:
+ *   JSON : {"results":[QueryWithConsensus...]} pretty-printed like serde_json::to_string_pretty (no runId/config:
+ *          runId is a random UUID and config belongs to the BLAST step)
+ *   JSONL: one QueryWithConsensus per line
+ * Free with blu_free_text. */
+int blu_build_consensus_identities(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
+                                   const char* taxonomies_file, const blu_pipeline_params* params, char** out_text,
+                                   size_t* out_len, blu_pipeline_stats* stats);
+void blu_free_text(char* text);
+
+/* CustomTaxon::from_file (domain/dtos/taxon.rs:28-66): .yaml or .json with the eight cutoff fields. */
+int blu_custom_taxon_from_file(const char* path, blu_cutoff_config* cfg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLU_PIPELINE_H */

@@ -1,0 +1,127 @@
+"""Drop-in use-case end to end on the GPU: outfmt-6 TSV + blutils DB JSON + custom cutoffs file in, the
+reference's result documents out (BASELINE config #1), compared field by field — consensus beans included —
+with the string-faithful oracle fed from an independent (Python) reading of the same files."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from blutils_amd import _native as N
+from blutils_amd import pipeline, synth
+from oracle import oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_inputs(tmp_path, tax, hits, use_taxid=False, scramble=True, half_scores=True):
+    lineages_text = tax.lineage_strings(text=True)
+    lineages_num = tax.lineage_strings(text=False)
+    db = {"blutilsVersion": "8.3.1", "ignoreTaxids": None, "replaceRank": None, "dropNonLinnaeanTaxonomies": None,
+          "sourceDatabase": "synthetic", "taxonomies": [
+              {"taxid": int(tax.taxid[t]), "rank": "species", "numericLineage": lineages_num[t],
+               "textLineage": lineages_text[t], "accessions": [{"accession": f"A{t}", "oid": str(t)}]} for t in range(tax.n)]}
+    tj = tmp_path / "tax.blutils.json"
+    tj.write_text(json.dumps(db))
+    seg = hits["seg_off"]
+    acc = hits["acc_rank"].view(np.uint32)
+    rows = []
+    rng = np.random.default_rng(9)
+    for q in range(len(seg) - 1):
+        s, e = int(seg[q]), int(seg[q + 1])
+        top = hits["bitscore"][s:e].max() if e > s else 0
+        for i in range(s, e):
+            t = int(hits["tax_row"][i])
+            taxid = int(tax.taxid[t]) if t >= 0 else 999999999
+            bs = int(hits["bitscore"][i])
+            # fractional scores truncate toward zero (mod.rs:184): x.5 on a non-top row stays below the top group
+            bs_txt = f"{bs}.5" if (half_scores and bs < top - 1 and rng.random() < 0.2) else (f"{bs}" if rng.random() < 0.5 else f"{bs}.0")
+            rows.append((q, f'q{q:08d}\tNR_{int(acc[i]):010d}.1\t{taxid}\t{hits["pident"][i]:.3f}\t{int(hits["align_len"][i])}'
+                            f'\t3\t1\t1\t400\t5\t404\t1e-120\t{bs_txt}'))
+    if scramble:   # rows of one query need not be contiguous; their relative (file) order must survive
+        order = sorted(range(len(rows)), key=lambda i: (rng.integers(0, 4), i))
+        rows = [rows[i] for i in order]
+    bt = tmp_path / "blast.out.tsv"
+    bt.write_text("\n".join(r[1] for r in rows) + "\n")
+    return str(bt), str(tj), [r[0] for r in rows]
+
+
+def _oracle_from_files(bt, tj, use_taxid, taxon, strategy, custom):
+    """Independent reading of the two files -> faithful oracle."""
+    db = json.load(open(tj))
+    lin = {int(t["taxid"]): (t["numericLineage"] if use_taxid else t["textLineage"]) for t in db["taxonomies"]}
+    lineages = list(dict.fromkeys(lin.values()))
+    lin_idx = {s: i for i, s in enumerate(lineages)}
+    per_q = {}
+    for line in open(bt):
+        c = line.rstrip("\n").split("\t")
+        per_q.setdefault(c[0], []).append(c)
+    names = list(per_q)
+    seg, acc_idx, accs, tax_row, pid, aln, bsc = [0], [], {}, [], [], [], []
+    for qn in names:
+        for c in per_q[qn]:
+            acc_idx.append(accs.setdefault(c[1], len(accs)))
+            tax_row.append(lin_idx[lin[int(c[2])]] if int(c[2]) in lin else -1)
+            pid.append(float(c[3])); aln.append(int(c[4])); bsc.append(int(float(c[12])))
+        seg.append(len(acc_idx))
+    tab = orc.HitTable(np.array(seg, np.uint64), np.array(acc_idx, np.uint32), list(accs), np.array(tax_row, np.int64),
+                       lineages, np.array(pid), np.array(aln, np.int64), np.array(bsc, np.int64))
+    res = orc.run(tab, taxon=taxon, strategy=strategy, custom=custom, threads=4).results()
+    return dict(zip(names, res))
+
+
+@pytest.mark.parametrize("strategy,use_taxid,fmt", [("relaxed", False, "json"), ("cautious", True, "jsonl")])
+def test_c1_files_through_the_pipeline(tmp_path, golden_dir, strategy, use_taxid, fmt):
+    tax = synth.make_taxonomy(2000, synth.SEEDS["C1"])
+    hits = synth.make_hits(tax, 1000, synth.SEEDS["C1"], 10, p_unmatched=0.002).numpy()
+    bt, tj, _ = _write_inputs(tmp_path, tax, hits, use_taxid)
+    vals = json.load(open(os.path.join(golden_dir, "custom_taxon_cutoffs_bacteria_16S.json")))["values"]
+    cy = tmp_path / "custom-taxon-cutoffs-bacteria-16S.yaml"
+    cy.write_text("".join(f"{k}: {v}\n" for k, v in vals.items()))
+    custom = pipeline.custom_taxon_from_file(str(cy))
+    headers = [f"q{q:08d}" for q in range(1000)] + ["fasta_only_1", "fasta_only_0"]
+    # strict mode mirrors the reference: a query on which it panics fails the call
+    with pytest.raises(N.BluError) as e:
+        pipeline.build_consensus_identities(bt, tj, "custom", strategy, use_taxid, custom, headers=headers, out_format=fmt)
+    assert e.value.code == pipeline.BLU_ERR_REFERENCE_PANIC
+    got, stats = pipeline.build_consensus_identities(bt, tj, "custom", strategy, use_taxid, custom, headers=headers,
+                                                     out_format=fmt, lenient=True)
+    assert stats["n_queries"] == 1000 and stats["n_hits"] == 10000 and stats["n_taxids"] == 2000
+    assert [g["query"] for g in got] == sorted(headers)                       # write_blutils_output.rs:111
+    assert len({g["runId"] for g in got}) == 1
+    exp = _oracle_from_files(bt, tj, use_taxid, "custom", strategy, custom)
+    n_found = 0
+    for g in got:
+        if g["query"].startswith("fasta_only"):
+            assert g["taxon"] is None                                          # mod.rs:86-102
+            continue
+        o = exp[g["query"]]
+        if o["status"] != orc.ST_CONSENSUS:
+            assert g["taxon"] is None, g["query"]
+            continue
+        n_found += 1
+        assert g["taxon"] == o["taxon"], (g["query"], g["taxon"], o["taxon"])  # every field, beans and accession order included
+    assert n_found > 900
+
+
+def test_json_text_layout(tmp_path):
+    """Byte layout of the JSON document = serde_json::to_string_pretty of BlutilsOutput{results, config: None}."""
+    (tmp_path / "t.json").write_text(json.dumps({"blutilsVersion": "x", "sourceDatabase": "y", "taxonomies": [
+        {"taxid": 10, "rank": "species", "numericLineage": "d__2;g__5;s__10", "textLineage": "d__bacteria;g__ba;s__ba-x", "accessions": []},
+        {"taxid": 11, "rank": "species", "numericLineage": "d__2;g__5;s__11", "textLineage": "d__bacteria;g__ba;s__ba-y", "accessions": []}]}))
+    (tmp_path / "b.tsv").write_text(
+        'q1\tACC_B.1\t11\t98.000\t400\t0\t0\t1\t400\t1\t400\t1e-50\t700\n'
+        '"q1"\tACC_A.1\t10\t99.500\t400\t0\t0\t1\t400\t1\t400\t1e-50\t700.9\n'
+        'q1\tACC_C.1\t10\t91.0\t380\t0\t0\t1\t400\t1\t400\t1e-40\t650\n')
+    raw, _ = pipeline.build_consensus_identities(str(tmp_path / "b.tsv"), str(tmp_path / "t.json"), "bacteria", "relaxed",
+                                                 parse=False)
+    doc = json.loads(raw)
+    run_id = doc["results"][0]["runId"]
+    expected = json.dumps({"results": [{"runId": run_id, "query": "q1", "taxon": {
+        "reachedRank": "genus", "maxAllowedRank": None, "identifier": "ba", "percIdentity": 99.5, "bitScore": 700.0,
+        "taxonomy": "d__bacteria;g__ba", "mutated": False, "singleMatch": False, "consensusBeans": [
+            {"rank": "species", "identifier": "ba-x", "occurrences": 1, "taxonomy": "d__bacteria;g__ba;s__ba-x", "accessions": ["ACC_A.1"]},
+            {"rank": "species", "identifier": "ba-y", "occurrences": 1, "taxonomy": "d__bacteria;g__ba;s__ba-y", "accessions": ["ACC_B.1"]}]}}],
+        "config": None}, indent=2)
+    assert raw == expected

@@ -23,6 +23,41 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert L.blu_abi_version() == 1
+    hdr2 = open(os.path.join(ROOT, "include", "blu_pipeline.h")).read()
+    declared2 = set(re.findall(r"\b(blu_[a-z0-9_]+)\s*\(", hdr2))
+    assert declared2 == set(N.PIPELINE_EXPORTS)
+    for name in declared2:
+        assert hasattr(L, name), name
+
+
+def test_custom_taxon_from_file(tmp_path, golden_dir):
+    """CustomTaxon::from_file (taxon.rs:28-66): the reference's assets YAML (as JSON fixture + re-written YAML)."""
+    import json
+    from blutils_amd import pipeline
+    vals = json.load(open(os.path.join(golden_dir, "custom_taxon_cutoffs_bacteria_16S.json")))["values"]
+    y = tmp_path / "cutoffs.yaml"
+    y.write_text("".join(f"{k}: {v}\n" for k, v in vals.items()))
+    assert pipeline.custom_taxon_from_file(str(y)) == vals
+    j = tmp_path / "cutoffs.json"
+    j.write_text(json.dumps({"domain": 55, "kingdom": None, "species": 98}))
+    assert pipeline.custom_taxon_from_file(str(j)) == {"domain": 55, "species": 98}
+    with pytest.raises(N.BluError):
+        pipeline.custom_taxon_from_file(str(tmp_path / "cutoffs.txt"))
+
+
+def test_pipeline_needs_a_device(tmp_path):
+    """The drop-in use-case has no CPU path either."""
+    import json
+    import torch
+    from blutils_amd import pipeline
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    (tmp_path / "t.json").write_text(json.dumps({"blutilsVersion": "x", "sourceDatabase": "y", "taxonomies": [
+        {"taxid": 1, "rank": "species", "numericLineage": "d__2;s__1", "textLineage": "d__b;s__x", "accessions": []}]}))
+    (tmp_path / "b.tsv").write_text("q1\tA.1\t1\t99.0\t400\t0\t0\t1\t400\t1\t400\t1e-50\t700\n")
+    with pytest.raises(N.BluError) as e:
+        pipeline.build_consensus_identities(str(tmp_path / "b.tsv"), str(tmp_path / "t.json"))
+    assert e.value.code == N.BLU_ERR_NO_DEVICE
 
 
 def test_result_record_layout():
