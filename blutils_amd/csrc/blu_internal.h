@@ -27,11 +27,8 @@ struct TaxDev {
     // Lineage rows in LEXICOGRAPHIC order of their node sequences (row index = "pos"):
     // word0 = len | shape << 8 (len 0 = bad lineage), words 1.. = node ids, root -> leaf.
     const uint32_t* lin;    // [n_tax][stride]
-    // engine row ids (blu_hits.tax_row) ARE these sorted positions.  Per row, one byte of lineage length
-    // (0 = bad lineage) — the only taxonomy data the streaming phase touches, 2.4 MB for 2.4 M taxids,
-    // L2-resident — and the rank-sequence shape id, read once per query for the reference row.
-    const uint8_t* len8;    // [n_tax]
-    const uint32_t* shape;  // [n_tax]
+    // Engine row ids (blu_hits.tax_row) = pos | lineage length << BLU_ROW_BITS (length 0 = bad lineage): the
+    // streaming phase needs no taxonomy lookup at all.  The shape id comes with the reference row's header word.
     // lcp8[i] = number of leading levels shared by sorted rows i and i+1.  In that order the levels shared by a
     // whole group of rows = min(lcp8[lo .. hi-1]) for the group's smallest/largest pos: a range-minimum query
     // replaces the per-row level scan of find_multi_taxa_consensus.rs:137-180.
@@ -43,6 +40,7 @@ struct TaxDev {
     uint64_t n_tax;
     uint32_t stride;        // words per lineage row, multiple of 16 (64-byte rows)
     uint32_t sc;            // entries per shape row
+    uint32_t max_depth;     // longest lineage: bounds the length bits of a (possibly corrupt) row id
 };
 
 struct HitsDev {
@@ -85,8 +83,6 @@ struct blu_taxonomy {
     uint32_t n_shapes = 0;
     std::unordered_map<int64_t, uint32_t> taxid_row;
     uint32_t* d_lin = nullptr;
-    uint8_t* d_len8 = nullptr;
-    uint32_t* d_shape = nullptr;
     std::vector<uint32_t> order;             // engine row id -> desc row
     uint8_t* d_lcp8 = nullptr;
     uint8_t* d_rmq = nullptr;

@@ -193,12 +193,13 @@ __device__ __forceinline__ uint32_t shared_levels(const TaxDev& t, uint32_t lo, 
 // Kernel A
 // ===============================================================================
 struct Entry {            // one top-group row in LDS, 24 bytes
-    uint32_t pos, aln, acc, pq;   // pos = engine row id (sorted lineage position); pq = position in the segment | query-in-task << 8
+    uint32_t id, aln, acc, pq;    // id = engine row id (sorted position | length << BLU_ROW_BITS); pq = position in the segment | query-in-task << 8
     double pid;
 };
 static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 
 #define META_SLOW 0x80000000u
+#define ROW_MASK ((1u << BLU_ROW_BITS) - 1u)
 // the five hit columns are read exactly once per run: non-temporal loads keep them from displacing the
 // lineage rows and cutoff tables (re-read by every query) in L2 / Infinity Cache
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -217,13 +218,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct WaveLds {
     Entry list[LIST_CAP];       // top-group rows of the task's queries, file order
-    uint32_t len[LIST_CAP];     // lineage length of list[i].pos; 0 = unmatched taxid (pos >= n_tax) or bad lineage
     uint32_t meta[WAVE + 4];    // first entry | k << 16, or META_SLOW
     uint2 seg[WAVE + 4];        // {first row relative to the task's first row, row count (0 if > 64)}
 };
 
+#ifndef BLU_WAVES_PER_SIMD
+#define BLU_WAVES_PER_SIMD 1
+#endif
 template <int STRAT>
-__global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
+__global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                        uint32_t* __restrict__ worklist,
                                                                        uint32_t* __restrict__ work_count) {
     __shared__ WaveLds s_lds[WAVES_A];
@@ -266,10 +269,6 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
         }
         // ---------------- phase 1: 4 queries per step, 16 lanes per query, 4 consecutive rows per lane ----------------
         const uint32_t grp = (uint32_t)lane >> 4, sub4 = ((uint32_t)lane & 15u) * 4u;
-        uint32_t g_len[4];   // lineage-length gathers of the previous step, written to LDS one step later
-        uint32_t g_idx[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { g_len[r] = 0; g_idx[r] = 0xFFFFFFFFu; }
         for (uint32_t qb = 0; qb < nq; qb += 4) {
             const uint32_t qi = qb + grp;                        // this lane's query (>= nq: empty slot of the table)
             const uint2 sg = L.seg[qi];
@@ -297,11 +296,6 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
             const u32x4 valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, voff, 0, STREAM_AUX);
             const u32x4 vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, voff, 0, STREAM_AUX);
 #endif
-            // the {header, pos} gathers of the previous step are older than these loads: they have landed by the
-            // time this step's data is used, so writing them out here never stalls
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (g_idx[r] != 0xFFFFFFFFu) L.len[g_idx[r]] = g_len[r];
             // every loaded register is read here on every path (see the note on vmcnt at the loop head)
             asm volatile("" ::"v"(vbs), "v"(vtax), "v"(vp01), "v"(vp23), "v"(valn), "v"(vacc));
 #ifdef BLU_EXP_NOREDUCE
@@ -333,30 +327,19 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                                   __hiloint2double((int)vp23.y, (int)vp23.x), __hiloint2double((int)vp23.w, (int)vp23.z)};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                g_idx[r] = 0xFFFFFFFFu;
 #ifdef BLU_EXP_NOLDS
                 if (false) {
 #else
                 if (fits && tt[r]) {
 #endif
                     Entry e;
-                    e.pos = xt[r]; e.aln = xa[r]; e.acc = xc[r]; e.pq = (sub4 + r) | (qi << 8); e.pid = xp[r];
-                    L.list[idx] = e;
-                    g_idx[r] = idx;
-                    // one byte per taxid (lineage length): the only taxonomy data phase 1 touches
-#ifdef BLU_EXP_P1ONLY
-                    g_len[r] = xt[r];
-#else
-                    g_len[r] = xt[r] < t.n_tax ? (uint32_t)t.len8[xt[r]] : 0u;
-#endif
+                    e.id = xt[r]; e.aln = xa[r]; e.acc = xc[r]; e.pq = (sub4 + r) | (qi << 8); e.pid = xp[r];
+                    L.list[idx] = e;   // the row id carries the lineage length: phase 1 touches no taxonomy table
                     ++idx;
                 }
             }
             if (fits) fill = p3 + k3;
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (g_idx[r] != 0xFFFFFFFFu) L.len[g_idx[r]] = g_len[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -367,7 +350,7 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
 #ifdef BLU_EXP_P1ONLY
         {
             uint4 pa, pb;
-            pack_status(pa, pb, 2, L.len[L.meta[lane] & 0xFF] + (uint32_t)L.list[L.meta[lane] & 0xFF].pid + L.list[L.meta[lane] & 0xFF].pos);
+            pack_status(pa, pb, 2, (uint32_t)L.list[L.meta[lane] & 0xFF].pid + L.list[L.meta[lane] & 0xFF].id);
             __builtin_amdgcn_wave_barrier();
             uint4* rec = reinterpret_cast<uint4*>(L.list);
             rec[2 * lane] = pa; rec[2 * lane + 1] = pb;
@@ -385,7 +368,7 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
         const uint64_t q = q0 + (uint32_t)lane;
         const uint32_t row0 = (uint32_t)my_off;
         // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
-        uint32_t mode = 3, r_len = 0, r_row = 0, r_pos = 0, minlen = 0, d = 0, rec_kind = 0;
+        uint32_t mode = 3, r_len = 0, r_row = 0, r_pos = 0, r_hdr = 0, minlen = 0, d = 0, rec_kind = 0;
         double r_pid = 0.0, max_pid = 0.0;
         uint4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
         if ((uint32_t)lane < nq) {
@@ -398,9 +381,9 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                 // parse errors first, in file order (find_single_query_consensus.rs:51-64), then NaN pident
                 uint32_t err = 0, err_pos = 0;
                 for (uint32_t e = 0; e < k; ++e) {
-                    const uint32_t hd = L.len[first + e];
-                    if (err == 0 && hd == 0) {
-                        err = L.list[first + e].pos >= t.n_tax ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE;
+                    const uint32_t id = L.list[first + e].id;
+                    if (err == 0 && ((id & ROW_MASK) >= t.n_tax || (id >> BLU_ROW_BITS) == 0)) {
+                        err = (id & ROW_MASK) >= t.n_tax ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE;
                         err_pos = L.list[first + e].pq & 0xFF;
                     }
                 }
@@ -418,10 +401,10 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                     minlen = 0xFFFFFFFFu;
                     for (uint32_t e = 0; e < k; ++e) {
                         const Entry x = L.list[first + e];
-                        const uint32_t len = L.len[first + e];
+                        const uint32_t len = umin(x.id >> BLU_ROW_BITS, t.max_depth), pos = x.id & ROW_MASK;
                         minlen = umin(minlen, len);
-                        lo = umin(lo, x.pos);
-                        hi = x.pos > hi ? x.pos : hi;
+                        lo = umin(lo, pos);
+                        hi = pos > hi ? pos : hi;
                         max_pid = x.pid > max_pid ? x.pid : max_pid;
                         const bool take = (e == 0) | key_better<STRAT>(len, x.pid, (int)x.aln, x.acc, b_len, r_pid, b_aln, b_acc);
                         b_len = take ? len : b_len;
@@ -429,10 +412,15 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                         r_pid = take ? x.pid : r_pid;
                         b_aln = take ? (int)x.aln : b_aln;
                         b_acc = take ? x.acc : b_acc;
-                        r_row = take ? x.pos : r_row;
+                        r_row = take ? pos : r_row;
                         r_pos = take ? (x.pq & 0xFF) : r_pos;
                     }
                     mode = k == 1 ? 2u : 0u;
+#ifndef BLU_EXP_LATE_HDR
+                    // start the reference row's fetch now (header word = shape id; the identifier sits in the same
+                    // 64-byte row): it overlaps the range-minimum lookups below instead of following them
+                    r_hdr = t.lin[(uint64_t)r_row * t.stride];
+#endif
                     // levels shared by the whole group (:137-180): every row agrees with the reference row on exactly
                     // the levels all rows share, and the scan never looks past the shortest lineage
                     d = minlen;
@@ -453,7 +441,16 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
             rec_kind = 1;
             if (!agree && d == 0) pack_status(ra, rb, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
             else {
-                const uint32_t len_ref = r_len, shape = t.shape[r_row];
+                // the reference row's header word gives the shape; the identifier read below hits the same 64-byte row
+#ifdef BLU_EXP_NOREF
+                const uint32_t* ref = t.lin;
+#else
+                const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
+#endif
+#ifdef BLU_EXP_LATE_HDR
+                r_hdr = ref[0];
+#endif
+                const uint32_t len_ref = r_len, shape = r_hdr >> 8;
                 const uint32_t b = single ? len_ref : (agree ? minlen - 1 : d - 1);
                 const double ident = (single | agree) ? r_pid : max_pid;
                 const double* cut = t.cut + (uint64_t)shape * t.sc;
@@ -480,11 +477,6 @@ __global__ __launch_bounds__(BLOCK_A) void blu_consensus_stream_kernel(HitsDev h
                     }
                 }
                 if (agree) A = F;                                                  // single hit / single-flag branch (:74-75)
-#ifdef BLU_EXP_NOREF
-                const uint32_t* ref = t.lin;
-#else
-                const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
-#endif
                 if (single) {
                     if (!A) pack_status(ra, rb, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, row0 + r_pos);   // find_single_query_consensus.rs:113-119
                     else {
@@ -610,8 +602,9 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             const double pid = c_pid[ii];
             const int aln = c_aln[ii];
             const uint32_t acc = c_acc[ii];
-            const bool unmatched = top && tax >= t.n_tax;
-            const uint32_t len = t.len8[(top && !unmatched) ? tax : 0u];
+            const uint32_t pos = tax & ROW_MASK;
+            const bool unmatched = top && pos >= t.n_tax;
+            const uint32_t len = umin(tax >> BLU_ROW_BITS, t.max_depth);
             const bool bad = top && !unmatched && len == 0;
             const uint64_t um = __ballot(unmatched), bm = __ballot(bad);
             if (um | bm) {   // parse_taxonomy Err at the first failing row (find_single_query_consensus.rs:58-60)
@@ -627,10 +620,10 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             b_aln = take ? aln : b_aln;
             b_acc = take ? acc : b_acc;
             b_pos = take ? i : b_pos;
-            b_row = take ? tax : b_row;
+            b_row = take ? pos : b_row;
             l_minlen = top ? umin(l_minlen, len) : l_minlen;
-            l_lo = top ? umin(l_lo, tax) : l_lo;
-            l_hi = (top && tax > l_hi) ? tax : l_hi;
+            l_lo = top ? umin(l_lo, pos) : l_lo;
+            l_hi = (top && pos > l_hi) ? pos : l_hi;
             l_maxpid = (top && pid > l_maxpid) ? pid : l_maxpid;
         }
         if (err_status) {
@@ -664,7 +657,7 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
         }
         const uint32_t row_ref = (uint32_t)rl((int)b_row, rlane);
         const uint32_t len_ref = (uint32_t)rl((int)b_len, rlane);
-        const uint32_t shape_ref = t.shape[row_ref];
+        const uint32_t shape_ref = t.lin[(uint64_t)row_ref * t.stride] >> 8;
         const uint32_t pos_ref = (uint32_t)rl((int)b_pos, rlane);
         const double pid_ref = rl_f64(b_pid, rlane);
         const bool in_l = (uint32_t)lane < len_ref;

@@ -172,7 +172,7 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
     if (desc->n_tax && (!desc->lin_off || !desc->lin_node || !desc->lin_rank)) {
         set_error("lineage arrays missing"); return BLU_ERR_INVALID_ARG;
     }
-    if (desc->n_tax >= 0xFFFFFFFFull) { set_error("n_tax must be < 2^32 - 1"); return BLU_ERR_INVALID_ARG; }
+    if (desc->n_tax >= (1ull << BLU_ROW_BITS)) { set_error("n_tax must be < 2^%u", BLU_ROW_BITS); return BLU_ERR_INVALID_ARG; }
     Backbone bb;
     int rc = make_backbone(*cfg, &bb);
     if (rc != BLU_OK) return rc;
@@ -279,17 +279,11 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         return a < b;
     });
     tax->pos_of.assign(n, 0);
-    for (uint64_t i = 0; i < n; ++i) tax->pos_of[order[i]] = (uint32_t)i;
+    for (uint64_t i = 0; i < n; ++i)   // engine row id: sorted position | lineage length << BLU_ROW_BITS
+        tax->pos_of[order[i]] = (uint32_t)i | ((L[(size_t)order[i] * stride] & 0xFF) << BLU_ROW_BITS);
     std::vector<uint32_t> lin_sorted((size_t)n * stride);
     for (uint64_t i = 0; i < n; ++i)
         memcpy(&lin_sorted[(size_t)i * stride], L + (size_t)order[i] * stride, stride * sizeof(uint32_t));
-    std::vector<uint8_t> len8(std::max<uint64_t>(n, 1) + 16, 0);
-    std::vector<uint32_t> shape_sorted(std::max<uint64_t>(n, 1), 0);
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint32_t hdr = lin_sorted[(size_t)i * stride];
-        len8[i] = (uint8_t)(hdr & 0xFF);
-        shape_sorted[i] = hdr >> 8;
-    }
     tax->order = order;
     const uint64_t n_lcp = n > 0 ? n - 1 : 0;
     const uint32_t nb = (uint32_t)((n_lcp + 15) / 16) + 1;            // 16-entry blocks (+1 block of padding)
@@ -326,19 +320,14 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
         if (e == hipSuccess) tax->num_cus = prop.multiProcessorCount;
         size_t b_lin = std::max<size_t>(lin_sorted.size(), 16) * sizeof(uint32_t);
-        size_t b_len8 = len8.size(), b_shape = shape_sorted.size() * sizeof(uint32_t);
         size_t b_cut = tax->h_cut.size() * sizeof(double);
         size_t b_codes = tax->h_codes.size() * sizeof(uint32_t);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lin, b_lin);
-        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_len8, b_len8);
-        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_shape, b_shape);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lcp8, lcp8.size());
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_rmq, rmq.size());
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_cut, b_cut);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_codes, b_codes);
         if (e == hipSuccess && !lin_sorted.empty()) e = hipMemcpy(tax->d_lin, lin_sorted.data(), lin_sorted.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(tax->d_len8, len8.data(), b_len8, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(tax->d_shape, shape_sorted.data(), b_shape, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_lcp8, lcp8.data(), lcp8.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_rmq, rmq.data(), rmq.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_cut, tax->h_cut.data(), b_cut, hipMemcpyHostToDevice);
@@ -348,7 +337,7 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
             blu_taxonomy_destroy(tax);
             return BLU_ERR_HIP;
         }
-        tax->device_bytes = b_lin + b_len8 + b_shape + lcp8.size() + rmq.size() + b_cut + b_codes;
+        tax->device_bytes = b_lin + lcp8.size() + rmq.size() + b_cut + b_codes;
     }
     *out = tax;
     return BLU_OK;
@@ -359,8 +348,6 @@ void blu_taxonomy_destroy(blu_taxonomy* tax) {
     if (tax->device >= 0) {
         (void)hipSetDevice(tax->device);
         if (tax->d_lin) (void)hipFree(tax->d_lin);
-        if (tax->d_len8) (void)hipFree(tax->d_len8);
-        if (tax->d_shape) (void)hipFree(tax->d_shape);
         if (tax->d_lcp8) (void)hipFree(tax->d_lcp8);
         if (tax->d_rmq) (void)hipFree(tax->d_rmq);
         if (tax->d_cut) (void)hipFree(tax->d_cut);

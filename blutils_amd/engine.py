@@ -105,8 +105,8 @@ class Taxonomy:
         return cut[:n], isdef[:n].astype(bool), codes[:n]
 
     def row_map(self):
-        """(desc row -> engine row id, engine row id -> desc row).  Engine row ids (what blu_hits.tax_row holds)
-        number the taxonomy rows in lexicographic lineage order."""
+        """(desc row -> engine row id, sorted position -> desc row).  Engine row ids (what blu_hits.tax_row holds)
+        are opaque: sorted position in lexicographic lineage order | lineage length << 25."""
         if getattr(self, "_row_map", None) is None:
             fwd = np.zeros(max(1, self.n_tax), dtype=np.uint32)
             inv = np.zeros(max(1, self.n_tax), dtype=np.uint32)
@@ -129,7 +129,7 @@ class Taxonomy:
         key = str(desc_rows.device)
         cache = self.__dict__.setdefault("_row_map_t", {})
         if key not in cache:
-            cache[key] = torch.from_numpy(fwd.astype(np.int64)).to(torch.int32).to(desc_rows.device)   # ids < 2^31
+            cache[key] = torch.from_numpy(fwd.view(np.int32).copy()).to(desc_rows.device)   # uint32 bit patterns
         m = cache[key]
         ok = (desc_rows >= 0) & (desc_rows < self.n_tax)
         return torch.where(ok, m[desc_rows.clamp(min=0, max=max(0, self.n_tax - 1)).long()], torch.full_like(desc_rows, -1))

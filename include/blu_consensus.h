@@ -30,6 +30,7 @@ extern "C" {
 #define BLU_ABI_VERSION 1u
 #define BLU_UNMATCHED_TAXID 0xFFFFFFFFu /* hit whose subject_taxid is not in the taxonomy (left join miss, mod.rs:72-76) */
 #define BLU_MAX_DEPTH 64u               /* level_mask is 64 bits wide */
+#define BLU_ROW_BITS 25u                /* engine row id = sorted position | lineage length << 25: at most 2^25 taxids */
 #define BLU_NONE_U8 0xFFu
 #define BLU_NONE_U16 0xFFFFu
 #define BLU_MAR_NEVER_EQUAL 0xFFFEu     /* Other("k")/Other("u"): a default-letter rank outside the backbone */
@@ -87,8 +88,9 @@ typedef struct blu_taxonomy blu_taxonomy; /* opaque; owns the device copy */
 typedef struct blu_hits {
     const int32_t* bitscore;   /* [n_hits] bit_score truncated toward zero to integer (mod.rs:184) */
     const uint32_t* tax_row;   /* [n_hits] ENGINE row id of subject_taxid (blu_taxonomy_lookup / blu_taxonomy_row_map:
-                                  the left join of mod.rs:72-76) or BLU_UNMATCHED_TAXID.  Engine row ids number the
-                                  taxonomy rows in lexicographic lineage order; they are NOT the desc row indices. */
+                                  the left join of mod.rs:72-76) or BLU_UNMATCHED_TAXID.  Engine row ids are opaque:
+                                  the row's rank in lexicographic lineage order (low BLU_ROW_BITS bits) and its lineage
+                                  length (bits above); they are NOT the desc row indices. */
     const double* pident;      /* [n_hits] perc_identity */
     const int32_t* align_len;  /* [n_hits] */
     const uint32_t* acc_rank;  /* [n_hits] order-preserving rank of subject_accession (bytewise String::cmp) */

@@ -22,5 +22,6 @@ with open(out + "/kernel_stats_blu.csv", "w") as f:
         w.writerow(r)
 print(json.dumps([{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs")} for r in keep], indent=1))
 PY
-scripts/pmc.sh $out/pmc "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" > $out/pmc.log 2>&1
+scripts/pmc.sh $out/pmc "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" > $out/pmc.log 2>&1
 tail -3 $out/pmc.log
+python3 scripts/probe/probe.py 12 > $out/stream_read_ceiling.txt 2>&1; tail -1 $out/stream_read_ceiling.txt

@@ -133,7 +133,9 @@ def test_taxid_lookup():
     rows = t.lookup(np.array([tax.taxid[5], 999999999, tax.taxid[299]], dtype=np.int64))
     fwd, inv = t.row_map()
     assert rows.tolist() == [int(fwd[5]), N.BLU_UNMATCHED_TAXID, int(fwd[299])]     # engine row ids
-    assert sorted(fwd.tolist()) == list(range(tax.n)) and (inv[fwd] == np.arange(tax.n)).all()
+    pos, length = fwd & ((1 << 25) - 1), fwd >> 25
+    assert sorted(pos.tolist()) == list(range(tax.n)) and (inv[pos] == np.arange(tax.n)).all()
+    assert (length == np.diff(tax.lin_off.astype(np.int64))).all()                  # the id carries the lineage length
     # engine row ids follow the lexicographic order of the lineages
     lin = [tuple(tax.lin_node[int(tax.lin_off[i]):int(tax.lin_off[i + 1])]) for i in inv]
     assert lin == sorted(lin)
