@@ -581,8 +581,23 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
         const int32_t* c_aln = h.align_len + start;
         const uint32_t* c_acc = h.acc_rank + start;
         // pass 1: top score
+        // 16-byte loads, four per lane in flight (1024 rows per iteration); rows past the segment read as 0 from the
+        // range-checked descriptor and are masked by index
+        const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)c_bs, 0, n * 4u, 0x00020000);
         int m = INT_MIN;
-        for (uint32_t i = lane; i < n; i += WAVE) m = imax(m, c_bs[i]);
+        for (uint32_t base = 0; base < n; base += 1024) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i0 = base + u * 256 + (uint32_t)lane * 4u;
+                m = imax(m, i0 < n ? (int)v[u].x : INT_MIN);
+                m = imax(m, i0 + 1 < n ? (int)v[u].y : INT_MIN);
+                m = imax(m, i0 + 2 < n ? (int)v[u].z : INT_MIN);
+                m = imax(m, i0 + 3 < n ? (int)v[u].w : INT_MIN);
+            }
+        }
         const int M = wave_max_i32(m);
         // pass 2: group size, errors in file order, lane-local best key / shortest lineage / max pident
         uint32_t k = 0, err_status = 0, err_row = 0;
@@ -590,10 +605,18 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
         uint32_t l_lo = 0xFFFFFFFFu, l_hi = 0;   // span of this lane's top rows in the sorted lineage order
         int b_aln = 0;
         double b_pid = 0.0, l_maxpid = 0.0;
-        for (uint32_t base = 0; base < n && err_status == 0; base += WAVE) {
+        for (uint32_t base4 = 0; base4 < n && err_status == 0; base4 += 4 * WAVE) {
+          // the bit-scores of four 64-row chunks are fetched together; top rows are sparse, so most chunks end at the ballot
+          int pre[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) pre[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_b, (base4 + u * WAVE + (uint32_t)lane) * 4u, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t base = base4 + u * WAVE;
+            if (base >= n || err_status != 0) break;
             const uint32_t i = base + (uint32_t)lane;
             const bool act = i < n;
-            const bool top = act && c_bs[act ? i : 0] == M;
+            const bool top = act && pre[u] == M;
             const uint64_t mask = __ballot(top);
             if (!mask) continue;
             k += (uint32_t)__builtin_popcountll(mask);
@@ -625,6 +648,7 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             l_lo = top ? umin(l_lo, pos) : l_lo;
             l_hi = (top && pos > l_hi) ? pos : l_hi;
             l_maxpid = (top && pid > l_maxpid) ? pid : l_maxpid;
+          }
         }
         if (err_status) {
             if (lane == 0) store_status(out, q, err_status, (uint32_t)start + err_row);
