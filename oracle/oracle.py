@@ -15,7 +15,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libblu_oracle.so")
+# BLU_ORACLE_LIB: e.g. the -fsanitize=address,undefined build (make -C oracle asan) for a sanitizer pass on the CPU
+_LIB_PATH = os.environ.get("BLU_ORACLE_LIB") or os.path.join(_HERE, "libblu_oracle.so")
 
 TAXON = {"fungi": 0, "bacteria": 1, "eukaryotes": 2, "custom": 3}
 STRATEGY = {"cautious": 0, "relaxed": 1}
@@ -44,6 +45,8 @@ def build(force: bool = False) -> str:
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
+    if os.environ.get("BLU_ORACLE_LIB"):
+        return _LIB_PATH
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "libblu_oracle.so"], check=True)
     return _LIB_PATH
