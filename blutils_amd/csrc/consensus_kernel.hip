@@ -234,12 +234,24 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     WaveLds& L = s_lds[wib];
     const uint64_t n_tasks = (h.n_queries + WAVE - 1) / WAVE;
+#ifdef BLU_WAVE_RECORDS
     const uint64_t wave = (uint64_t)blockIdx.x * WAVES_A + wib;
     const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_A;
 
     for (uint64_t task = wave; task < n_tasks; task += n_waves) {
         const uint64_t q0 = task * WAVE;
         const uint32_t nq = (uint32_t)((h.n_queries - q0) < WAVE ? (h.n_queries - q0) : WAVE);
+#else
+    // The block's four waves take four CONSECUTIVE tasks and meet at a barrier before their records leave: one
+    // contiguous 8 KiB write burst per block instead of four separate 2 KiB ones.  A record stream of 2.6 % of the
+    // bytes costs the HBM read stream far more than its share when it arrives as small isolated writes
+    // (scripts/probe/pattern_probe.hip: 2 KiB bursts +0.49 ms, 8 KiB +0.23 ms, 32 KiB +0.08 ms on a 1.9 ms stream).
+    const uint64_t n_btasks = (n_tasks + WAVES_A - 1) / WAVES_A;
+    for (uint64_t bt = blockIdx.x; bt < n_btasks; bt += gridDim.x) {
+        const uint64_t task = bt * WAVES_A + wib;
+        const uint64_t q0 = task * WAVE;
+        const uint32_t nq = task < n_tasks ? (uint32_t)((h.n_queries - q0) < WAVE ? (h.n_queries - q0) : WAVE) : 0u;
+#endif
         // lane i holds the row range of query q0 + i
         uint64_t my_off = 0, my_end = 0;
         if ((uint32_t)lane < nq) {
@@ -511,6 +523,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         // write-through + non-temporal (sc1 nt): a record is written once and never read by the GPU; letting the
         // lines sit dirty in L2 until the read stream evicts them one by one costs ~2x more HBM time (probe:
         // scripts/probe/pattern_probe.hip store modes 1 vs 18)
+#ifdef BLU_WAVE_RECORDS
         const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + q0), 0, nq * 32u, 0x00020000);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -523,6 +536,26 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+#else
+        __syncthreads();   // all four tasks' records are staged
+        {
+            const uint64_t bq0 = bt * WAVES_A * WAVE;                       // first query of the block's four tasks
+            const uint64_t left = h.n_queries - bq0;
+            const uint32_t bnq = left < WAVES_A * WAVE ? (uint32_t)left : WAVES_A * WAVE;
+            const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + bq0), 0, bnq * 32u, 0x00020000);
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const uint32_t c = threadIdx.x + BLOCK_A * part;            // 16-byte chunk of the block's 8 KiB
+                const uint32_t w = c >> 7, cc = c & 127u, qc = cc >> 1;      // owning wave, chunk and query inside its task
+                if ((uint64_t)w * WAVE + qc < bnq && s_lds[w].meta[qc]) {
+                    const uint4 v = reinterpret_cast<const uint4*>(s_lds[w].list)[cc];
+                    const u32x4 x = {v.x, v.y, v.z, v.w};
+                    __builtin_amdgcn_raw_buffer_store_b128(x, rs_out, c * 16u, 0, RECORD_AUX);
+                }
+            }
+        }
+        __syncthreads();   // the staging area is the next task's list
+#endif
     }
 }
 

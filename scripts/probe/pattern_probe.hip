@@ -68,6 +68,15 @@ __global__ __launch_bounds__(256) void pattern_kernel(const int* __restrict__ c0
             else if (store_mode == 17) { __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane * 16, 0, 17); __builtin_amdgcn_raw_buffer_store_b128(v, rs, 1024 + lane * 16, 0, 17); }
             else if (store_mode == 18) { __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane * 16, 0, 18); __builtin_amdgcn_raw_buffer_store_b128(v, rs, 1024 + lane * 16, 0, 18); }
             else { __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane * 16, 0, 1); __builtin_amdgcn_raw_buffer_store_b128(v, rs, 1024 + lane * 16, 0, 1); }
+        } else if (store_mode == 7 || store_mode == 8) {   // sc1 nt bursts: 8 KiB every 4th task (7) / 32 KiB every 16th task (8)
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            const uint64_t it = task / n_waves;
+            const int per = store_mode == 7 ? 4 : 16;
+            if ((it % per) == (uint64_t)(per - 1)) {
+                const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(outp + (task - (per - 1) * n_waves) * 128), 0, 2048 * per, 0x00020000);
+                u4 v = {acc, 1, 2, 3};
+                for (int j = 0; j < 2 * per; ++j) __builtin_amdgcn_raw_buffer_store_b128(v, rs, j * 1024 + lane * 16, 0, 18);
+            }
         } else if (store_mode == 4) {   // half the bytes: 16 B per segment
             outp[task * 64 + lane] = make_uint4(acc, 1, 2, 3);
         } else if (store_mode == 5) {   // same bytes, 4x fewer/larger bursts: 8 KiB every 4th task of the wave
