@@ -1,0 +1,63 @@
+"""`blu`-compatible driver for the consensus step.
+
+    python -m blutils_amd.cli blastn build-consensus BLAST_OUT -t TAX.json --taxon bacteria --strategy relaxed
+        [-c CUTOFFS.yaml] [-u] [--blutils-out-file OUT] [--out-format json|jsonl|yaml]
+
+Same arguments as the reference's `blu blastn build-consensus`
+(ports/cli/src/cmds/blast/commands.rs:105-143, cmds/blast/mod.rs:104-146): without --blutils-out-file the
+document goes to stdout (compact JSON, as serde_json::to_writer prints it); with it, the extension is forced to
+the format's (write_blutils_output.rs:39-52) and JSON is pretty-printed.  The BLAST fan-out
+(`run-with-consensus`) and the DB builders are not part of this engine."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+from . import pipeline
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="blu", description="MI355X-native consensus step of blutils")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    blastn = sub.add_parser("blastn").add_subparsers(dest="sub", required=True)
+    bc = blastn.add_parser("build-consensus", help="consensus identities from a BLAST outfmt-6 table")
+    bc.add_argument("blast_out")
+    bc.add_argument("-t", "--tax-file", required=True)
+    bc.add_argument("--blutils-out-file")
+    bc.add_argument("--taxon", required=True, choices=["fungi", "bacteria", "eukaryotes", "custom"])
+    bc.add_argument("-c", "--custom-taxon-cutoff-file")
+    bc.add_argument("--strategy", required=True, choices=["cautious", "relaxed"])
+    bc.add_argument("-u", "--use-taxid", action="store_true")
+    bc.add_argument("--out-format", default="json", choices=["json", "jsonl", "yaml"])
+    bc.add_argument("--device", type=int, default=0, help="HIP device ordinal (not in the reference CLI)")
+    return ap
+
+
+def main(argv=None) -> int:
+    args = build_parser().parse_args(argv)
+    custom = None
+    if args.custom_taxon_cutoff_file:
+        custom = pipeline.custom_taxon_from_file(args.custom_taxon_cutoff_file)        # CustomTaxon::from_file
+    elif args.taxon == "custom":
+        # cmds/blast/mod.rs:114-117
+        raise SystemExit("Custom taxon values are required when the custom taxon option is selected.")
+    to_file = args.blutils_out_file is not None
+    fmt = args.out_format if (to_file or args.out_format != "json") else "json-compact"
+    text, _ = pipeline.build_consensus_identities(args.blast_out, args.tax_file, args.taxon, args.strategy,
+                                                  args.use_taxid, custom, headers=None, out_format=fmt,
+                                                  device=args.device, parse=False)
+    if to_file:
+        path = os.path.splitext(args.blutils_out_file)[0] + "." + args.out_format      # PathBuf::set_extension
+        parent = os.path.dirname(path)
+        if parent and not os.path.exists(parent):
+            os.makedirs(parent)
+        with open(path, "w") as f:
+            f.write(text)
+    else:
+        sys.stdout.write(text)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

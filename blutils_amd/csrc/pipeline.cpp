@@ -360,10 +360,46 @@ void json_f64(std::string& o, double v) {   // serde_json: shortest digits that 
     o += s;
 }
 
+// serde_yaml 0.9 scalar style (third-party emitter, approximated): plain when the text cannot be read back as
+// anything but that string, single quotes otherwise, double quotes when it holds control characters.
+void yaml_str(std::string& o, const std::string& s) {
+    static const char* reserved[] = {"null", "Null", "NULL", "~", "true", "True", "TRUE", "false", "False", "FALSE",
+                                     "y", "Y", "yes", "Yes", "YES", "n", "N", "no", "No", "NO", "on", "On", "ON", "off", "Off", "OFF"};
+    bool plain = !s.empty();
+    bool control = false;
+    for (unsigned char c : s) if (c < 0x20 || c == 0x7F) control = true;
+    if (plain) {
+        const unsigned char f = (unsigned char)s[0];
+        if (!(isalpha(f) || f == '_' || f == '/')) plain = false;               // digits, '-', '.', indicators, spaces
+        for (const char* r : reserved) if (s == r) plain = false;
+        if (s.back() == ' ' || s.back() == ':') plain = false;
+        if (s.find(": ") != std::string::npos || s.find(" #") != std::string::npos) plain = false;
+        for (unsigned char c : s) if (c >= 0x80 || c == '"' || c == '\'' || c == '\\' || c == '`') { /* allowed in plain */ }
+    }
+    if (control) {
+        o.push_back('"');
+        for (unsigned char c : s) {
+            if (c == '"' || c == '\\') { o.push_back('\\'); o.push_back((char)c); }
+            else if (c == '\n') o += "\\n";
+            else if (c == '\t') o += "\\t";
+            else if (c < 0x20 || c == 0x7F) { char b[8]; snprintf(b, sizeof b, "\\x%02x", c); o += b; }
+            else o.push_back((char)c);
+        }
+        o.push_back('"');
+    } else if (plain) {
+        o += s;
+    } else {
+        o.push_back('\'');
+        for (char c : s) { if (c == '\'') o.push_back('\''); o.push_back(c); }
+        o.push_back('\'');
+    }
+}
+
 struct Renderer {
     const Db& db;
     const HitTable& ht;
     const blu_taxonomy* tax;
+    struct Bean { std::string rank_serde, identifier, taxonomy; int32_t occurrences = 0; std::vector<std::string> accessions; uint32_t node = 0; };
     std::string lineage_string(uint32_t desc_row) const {   // taxonomy_beans_to_string (taxonomy_bean.rs:38-45)
         std::string s;
         for (uint64_t i = db.lin_off[desc_row]; i < db.lin_off[desc_row + 1]; ++i) {
@@ -377,10 +413,40 @@ struct Renderer {
         blu_taxonomy_row_cutoffs(tax, desc_row, BLU_MAX_DEPTH, nullptr, nullptr, codes);
         return blu_taxonomy_rank_name(tax, codes[level], 1);
     }
-    struct Bean { std::string rank_serde, identifier, taxonomy; int32_t occurrences = 0; std::vector<std::string> accessions; uint32_t node; };
-
+    struct Fields { std::string reached, mar, identifier, taxonomy; bool has_mar = false, mutated = false, single = false; double pid = 0, bs = 0; std::vector<Bean> beans; };
+    void taxon_yaml(std::string& o, uint64_t q, const blu_result& r) const {
+        std::string js;
+        Fields f;
+        fields(q, r, f);
+        auto kv = [&](const char* k) { o += "    "; o += k; o += ": "; };
+        kv("reachedRank"); yaml_str(o, f.reached); o.push_back('\n');
+        kv("maxAllowedRank"); if (f.has_mar) yaml_str(o, f.mar); else o += "null"; o.push_back('\n');
+        kv("identifier"); yaml_str(o, f.identifier); o.push_back('\n');
+        kv("percIdentity"); json_f64(o, f.pid); o.push_back('\n');
+        kv("bitScore"); json_f64(o, f.bs); o.push_back('\n');
+        kv("taxonomy"); yaml_str(o, f.taxonomy); o.push_back('\n');
+        kv("mutated"); o += f.mutated ? "true" : "false"; o.push_back('\n');
+        kv("singleMatch"); o += f.single ? "true" : "false"; o.push_back('\n');
+        if (f.beans.empty()) { kv("consensusBeans"); o += "[]\n"; return; }
+        o += "    consensusBeans:\n";
+        for (const Bean& b : f.beans) {
+            o += "    - rank: "; yaml_str(o, b.rank_serde); o.push_back('\n');
+            o += "      identifier: "; yaml_str(o, b.identifier); o.push_back('\n');
+            o += "      occurrences: " + std::to_string(b.occurrences) + "\n";
+            o += "      taxonomy: "; yaml_str(o, b.taxonomy); o.push_back('\n');
+            if (b.accessions.empty()) { o += "      accessions: []\n"; continue; }
+            o += "      accessions:\n";
+            for (const std::string& a : b.accessions) { o += "      - "; yaml_str(o, a); o.push_back('\n'); }
+        }
+    }
+    // the reference's TaxonomyBean fields of one record (shared by the JSON and YAML writers)
+    void fields(uint64_t q, const blu_result& r, Fields& f) const {
+        std::string tmp;
+        taxon_impl(tmp, q, r, false, 0, &f);
+    }
     // pretty = serde_json::to_string_pretty layout (2-space indent); ind = indentation of the object's own line
-    void taxon(std::string& o, uint64_t q, const blu_result& r, bool pretty, int ind) const {
+    void taxon(std::string& o, uint64_t q, const blu_result& r, bool pretty, int ind) const { taxon_impl(o, q, r, pretty, ind, nullptr); }
+    void taxon_impl(std::string& o, uint64_t q, const blu_result& r, bool pretty, int ind, Fields* out_fields) const {
         auto nl = [&](int extra) { if (pretty) { o.push_back('\n'); o.append((size_t)(ind + extra) * 2, ' '); } };
         const char* colon = pretty ? ": " : ":";
         const uint32_t row = r.ref_row, drow = ht.tax_desc_row[row];
@@ -439,6 +505,24 @@ struct Renderer {
                 if (a.occurrences != b.occurrences) return a.occurrences > b.occurrences;
                 return a.identifier < b.identifier;
             });
+        }
+        if (out_fields) {
+            Fields& f = *out_fields;
+            f.reached = blu_taxonomy_rank_name(tax, r.reached_rank, 1);
+            f.has_mar = r.max_allowed_level != BLU_NONE_U8;
+            if (f.has_mar) {
+                uint8_t isdef[BLU_MAX_DEPTH]; uint16_t codes[BLU_MAX_DEPTH];
+                blu_taxonomy_row_cutoffs(tax, drow, BLU_MAX_DEPTH, nullptr, isdef, codes);
+                f.mar = blu_taxonomy_rank_name(tax, codes[r.max_allowed_level], isdef[r.max_allowed_level] ? 1 : 0);
+            }
+            f.identifier = db.node_ident[r.identifier_node];
+            f.taxonomy = taxonomy;
+            f.mutated = (r.flags & BLU_FLAG_MUTATED) != 0;
+            f.single = single;
+            f.pid = ht.pident[row];
+            f.bs = (double)ht.bitscore[row];
+            f.beans = std::move(beans);
+            return;
         }
         o.push_back('{');
         nl(1); o += "\"reachedRank\""; o += colon; json_str(o, blu_taxonomy_rank_name(tax, r.reached_rank, 1));
@@ -511,7 +595,6 @@ int blu_build_consensus_identities(const char* blast_output_file, const char* co
     if (!blast_output_file || !taxonomies_file || !params || !out_text) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
     *out_text = nullptr;
     if (out_len) *out_len = 0;
-    if (params->out_format == BLU_OUT_YAML) { set_error("YAML output is not implemented yet (JSON and JSONL are)"); return BLU_ERR_INVALID_ARG; }
     blu_pipeline_stats st{};
     double t0 = now_s();
     Db db;
@@ -582,18 +665,34 @@ int blu_build_consensus_identities(const char* blast_output_file, const char* co
         }
     }
     const bool pretty = params->out_format == BLU_OUT_JSON;
+    const bool doc = pretty || params->out_format == BLU_OUT_JSON_COMPACT;   // one {results, config} document
     const std::string run_id = uuid_v4();
     Renderer R{db, ht, tax};
     std::string o;
     o.reserve(items.size() * 512);
     if (pretty) o += "{\n  \"results\": [";
+    else if (doc) o += "{\"results\":[";
     else o += "null\n";                                               // JSONL: the (absent) config line comes first
+    if (params->out_format == BLU_OUT_YAML) {
+        o.clear();
+        o += items.empty() ? "results: []\n" : "results:\n";
+        for (const Item& it : items) {
+            o += "- runId: "; yaml_str(o, run_id); o.push_back('\n');
+            o += "  query: "; yaml_str(o, *it.name); o.push_back('\n');
+            if (it.q < 0 || recs[(size_t)it.q].status >= 2) { o += "  taxon: null\n"; continue; }
+            o += "  taxon:\n";
+            R.taxon_yaml(o, (uint64_t)it.q, recs[(size_t)it.q]);
+        }
+        o += "config: null\n";
+    }
     bool first = true;
+    if (params->out_format != BLU_OUT_YAML)
     for (const Item& it : items) {
         const int ind = pretty ? 2 : 0;
         auto nl = [&](int extra) { if (pretty) { o.push_back('\n'); o.append((size_t)(ind + extra) * 2, ' '); } };
         const char* colon = pretty ? ": " : ":";
         if (pretty) { if (!first) o.push_back(','); nl(0); }
+        else if (doc && !first) o.push_back(',');
         first = false;
         o.push_back('{');
         nl(1); o += "\"runId\""; o += colon; json_str(o, run_id);
@@ -602,9 +701,11 @@ int blu_build_consensus_identities(const char* blast_output_file, const char* co
         if (it.q < 0 || recs[(size_t)it.q].status >= 2) o += "null";
         else R.taxon(o, (uint64_t)it.q, recs[(size_t)it.q], pretty, ind + 1);
         nl(0); o.push_back('}');
-        if (!pretty) o.push_back('\n');
+        if (!doc) o.push_back('\n');
     }
-    if (pretty) { if (!items.empty()) o += "\n  "; o += "],\n  \"config\": null\n}"; }
+    if (params->out_format == BLU_OUT_YAML) {}
+    else if (pretty) { if (!items.empty()) o += "\n  "; o += "],\n  \"config\": null\n}"; }
+    else if (doc) o += "],\"config\":null}";
     st.t_render_s = now_s() - t0;
     blu_taxonomy_destroy(tax);
     char* buf = (char*)malloc(o.size() + 1);

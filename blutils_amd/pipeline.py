@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 
 from . import _native as N
 
-OUT_FORMAT = {"json": 0, "jsonl": 1, "yaml": 2}
+OUT_FORMAT = {"json": 0, "jsonl": 1, "yaml": 2, "json-compact": 3}
 BLU_ERR_REFERENCE_PANIC = 9
 
 
@@ -86,8 +86,11 @@ def build_consensus_identities(blast_output: str, taxonomies_file: str, taxon: s
     stats = {f: getattr(st, f) for f, _ in PipelineStats._fields_}
     if not parse:
         return raw, stats
-    if out_format == "json":
+    if out_format in ("json", "json-compact"):
         return json.loads(raw)["results"], stats
+    if out_format == "yaml":
+        import yaml
+        return yaml.safe_load(raw)["results"], stats
     lines = raw.splitlines()
     assert lines[0] == "null"   # the (absent) config line (write_blutils_output.rs:169-175)
     return [json.loads(l) for l in lines[1:]], stats

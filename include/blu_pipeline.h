@@ -27,7 +27,8 @@ extern "C" {
 #endif
 
 /* write_blutils_output.rs:20-31 OutputFormat */
-enum blu_out_format { BLU_OUT_JSON = 0, BLU_OUT_JSONL = 1, BLU_OUT_YAML = 2 };
+enum blu_out_format { BLU_OUT_JSON = 0, BLU_OUT_JSONL = 1, BLU_OUT_YAML = 2,
+                      BLU_OUT_JSON_COMPACT = 3 /* serde_json::to_writer: what the CLI prints to stdout (:152-163) */ };
 
 typedef struct blu_pipeline_params {
     blu_cutoff_config cutoffs;   /* taxon + Option<CustomTaxon> */
@@ -50,9 +51,12 @@ typedef struct blu_pipeline_stats {
 /* Runs the whole use-case.  headers/n_headers: Option<Vec<String>> of FASTA ids (NULL/0 = None): ids without a
  * hit row become NoConsensusFound entries (mod.rs:86-102).  On success *out_text is a malloc'd buffer with the
  * serialized results, sorted by query (write_blutils_output.rs:111), in `out_format`:
- *   JSON : {"results":[QueryWithConsensus...]} pretty-printed like serde_json::to_string_pretty (no runId/config:
- *          runId is a random UUID and config belongs to the BLAST step)
- *   JSONL: one QueryWithConsensus per line
+ *   JSON : {"results":[QueryWithConsensus...],"config":null} pretty-printed like serde_json::to_string_pretty
+ *          (runId is a fresh UUID v4 per call; config is None on this path, cmds/blast/mod.rs:137-142)
+ *   JSON_COMPACT: the same document on one line
+ *   JSONL: the config line (`null`) then one QueryWithConsensus per line
+ *   YAML : block style as serde_yaml 0.9 emits BlutilsOutput (scalar quoting rules of the third-party emitter are
+ *          approximated: parity unpinned there)
  * Free with blu_free_text. */
 int blu_build_consensus_identities(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
                                    const char* taxonomies_file, const blu_pipeline_params* params, char** out_text,

@@ -125,3 +125,38 @@ def test_json_text_layout(tmp_path):
             {"rank": "species", "identifier": "ba-y", "occurrences": 1, "taxonomy": "d__bacteria;g__ba;s__ba-y", "accessions": ["ACC_B.1"]}]}}],
         "config": None}, indent=2)
     assert raw == expected
+
+
+def test_cli_and_yaml(tmp_path, capsys):
+    """`blu blastn build-consensus` arguments (commands.rs:105-143): stdout = compact JSON, file = pretty JSON with the
+    extension forced; YAML carries the same values as JSON (numeric identifiers stay strings)."""
+    from blutils_amd import cli
+    tax = synth.make_taxonomy(300, 3)
+    hits = synth.make_hits(tax, 120, 4, 8, p_unmatched=0.0).numpy()
+    hits["pident"][:] = np.maximum(hits["pident"], 61.0)          # no panics: the CLI mirrors the strict reference
+    bt, tj, _ = _write_inputs(tmp_path, tax, hits, use_taxid=True, scramble=False)
+    # level-0 disagreements make the reference panic: drop those queries from the file for the strict CLI run
+    lenient, _ = pipeline.build_consensus_identities(bt, tj, "bacteria", "relaxed", True, lenient=True)
+    bad = {g["query"] for g in lenient if g["taxon"] is None}
+    lines = [l for l in open(bt) if l.split("\t")[0] not in bad]
+    open(bt, "w").writelines(lines)
+    base = ["blastn", "build-consensus", bt, "-t", tj, "--taxon", "bacteria", "--strategy", "relaxed", "-u"]
+    assert cli.main(base) == 0
+    out = capsys.readouterr().out
+    assert "\n" not in out.strip() and out.startswith('{"results":[{"runId":"')
+    doc = json.loads(out)
+    assert doc["config"] is None and len(doc["results"]) == 120 - len(bad)
+    assert cli.main(base + ["--blutils-out-file", str(tmp_path / "res.txt")]) == 0
+    pretty = json.load(open(tmp_path / "res.json"))                                   # extension forced to .json
+    strip = lambda rs: [{k: v for k, v in r.items() if k != "runId"} for r in rs]
+    assert strip(pretty["results"]) == strip(doc["results"])
+    assert cli.main(base + ["--blutils-out-file", str(tmp_path / "res"), "--out-format", "yaml"]) == 0
+    import yaml
+    y = yaml.safe_load(open(tmp_path / "res.yaml"))
+    assert y["config"] is None and strip(y["results"]) == strip(doc["results"])
+    assert all(isinstance(r["taxon"]["identifier"], str) for r in y["results"])      # '1234' stays a string
+    assert cli.main(base + ["--blutils-out-file", str(tmp_path / "res"), "--out-format", "jsonl"]) == 0
+    jl = open(tmp_path / "res.jsonl").read().splitlines()
+    assert jl[0] == "null" and strip([json.loads(l) for l in jl[1:]]) == strip(doc["results"])
+    with pytest.raises(SystemExit):
+        cli.main(["blastn", "build-consensus", bt, "-t", tj, "--taxon", "custom", "--strategy", "relaxed"])
