@@ -24,6 +24,7 @@
 #include <cstring>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -257,81 +258,171 @@ std::string strip_quotes(std::string_view v) {   // mod.rs:169-172 `.replace("\"
     return s;
 }
 
-int load_hits(const char* path, const Db& db, HitTable& ht) {
-    MappedFile f;
-    if (!f.open(path)) { set_error("Unexpected error occurred on load table: %s", path); return BLU_ERR_IO; }
-    struct Row { uint32_t q, acc, tax; int32_t bs, aln; double pid; };
-    std::vector<Row> rows;
-    std::unordered_map<std::string, uint32_t> qids, accids;
-    std::vector<uint32_t> per_query;
-    const char* p = f.data;
-    const char* end = f.data + f.size;
+// Parses one number the way the columns are typed (mod.rs:226-244); std::from_chars first (no allocation), strtod as
+// the fallback for forms from_chars refuses (leading '+', hex floats ...).
+bool parse_f64(std::string_view v, double* out) {
+    const char* b = v.data();
+    const char* e = b + v.size();
+    while (b < e && (*b == ' ')) ++b;
+    auto r = std::from_chars(b, e, *out);
+    if (r.ec == std::errc() && r.ptr == e) return true;
+    std::string tmp(v);
+    char* endp = nullptr;
+    *out = strtod(tmp.c_str(), &endp);
+    return endp != tmp.c_str();
+}
+
+struct RawRow { std::string_view q, acc; uint32_t tax; int32_t bs, aln; double pid; };
+
+// One worker's share of the file: [begin, end) starts and ends on line boundaries.
+struct Chunk {
+    const char* begin = nullptr;
+    const char* end = nullptr;
+    std::vector<RawRow> rows;
+    uint64_t unmatched = 0, first_line = 0, n_lines = 0;
+    int rc = BLU_OK;
+    std::string err;
+};
+
+void parse_chunk(Chunk& c, const Db& db, const char* path) {
+    const char* p = c.begin;
     uint64_t line_no = 0;
-    while (p < end) {
-        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-        const char* le = nl ? nl : end;
+    c.rows.reserve((size_t)(c.end - c.begin) / 96 + 16);
+    while (p < c.end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(c.end - p));
+        const char* le = nl ? nl : c.end;
         const char* lend = le;
         if (lend > p && lend[-1] == '\r') --lend;
         ++line_no;
         if (lend > p) {
             std::string_view col[13];
             int nc = 0;
-            const char* c = p;
+            const char* s = p;
             while (nc < 13) {
-                const char* tab = (const char*)memchr(c, '\t', (size_t)(lend - c));
+                const char* tab = (const char*)memchr(s, '\t', (size_t)(lend - s));
                 const char* ce = tab ? tab : lend;
-                col[nc++] = std::string_view(c, (size_t)(ce - c));
+                col[nc++] = std::string_view(s, (size_t)(ce - s));
                 if (!tab) break;
-                c = tab + 1;
+                s = tab + 1;
             }
-            if (nc < 13) { set_error("line %llu of %s has %d columns, outfmt-6 with 13 expected (mod.rs:226-244)", (unsigned long long)line_no, path, nc); return BLU_ERR_PARSE; }
-            auto num = [&](std::string_view v, double* out) {
-                std::string tmp(v);
-                char* e = nullptr;
-                *out = strtod(tmp.c_str(), &e);
-                return e != tmp.c_str();
-            };
+            char msg[512];
+            if (nc < 13) {
+                snprintf(msg, sizeof msg, "line %llu(+%llu) of %s has %d columns, outfmt-6 with 13 expected (mod.rs:226-244)",
+                         (unsigned long long)line_no, (unsigned long long)c.first_line, path, nc);
+                c.rc = BLU_ERR_PARSE; c.err = msg; return;
+            }
             double taxid_f, pid, aln, bs;
-            if (!num(col[2], &taxid_f) || !num(col[3], &pid) || !num(col[4], &aln) || !num(col[12], &bs)) {
-                set_error("line %llu of %s: numeric column does not parse", (unsigned long long)line_no, path); return BLU_ERR_PARSE;
+            if (!parse_f64(col[2], &taxid_f) || !parse_f64(col[3], &pid) || !parse_f64(col[4], &aln) || !parse_f64(col[12], &bs)) {
+                snprintf(msg, sizeof msg, "line %llu(+%llu) of %s: numeric column does not parse", (unsigned long long)line_no,
+                         (unsigned long long)c.first_line, path);
+                c.rc = BLU_ERR_PARSE; c.err = msg; return;
             }
             const double bs_t = std::trunc(bs);               // mod.rs:184 AnyValue::Float64 -> try_extract::<i64>
             if (!(bs_t >= -2147483648.0 && bs_t <= 2147483647.0) || !(aln >= -2147483648.0 && aln <= 2147483647.0)) {
-                set_error("line %llu of %s: bit_score / align_length outside the 32-bit range of the engine columns", (unsigned long long)line_no, path); return BLU_ERR_PARSE;
+                snprintf(msg, sizeof msg, "line %llu(+%llu) of %s: bit_score / align_length outside the 32-bit range of the engine columns",
+                         (unsigned long long)line_no, (unsigned long long)c.first_line, path);
+                c.rc = BLU_ERR_PARSE; c.err = msg; return;
             }
-            Row r;
-            std::string q = strip_quotes(col[0]), a = strip_quotes(col[1]);
-            auto qi = qids.find(q);
-            if (qi == qids.end()) { qi = qids.emplace(q, (uint32_t)ht.query_names.size()).first; ht.query_names.push_back(q); per_query.push_back(0); }
-            auto ai = accids.find(a);
-            if (ai == accids.end()) { ai = accids.emplace(a, (uint32_t)ht.accessions.size()).first; ht.accessions.push_back(a); }
-            r.q = qi->second; r.acc = ai->second;
+            RawRow r;
+            r.q = col[0]; r.acc = col[1];
             auto ti = db.row_of.find((int64_t)taxid_f);
             r.tax = ti == db.row_of.end() ? BLU_UNMATCHED_TAXID : ti->second;    // left join (mod.rs:72-76)
-            if (r.tax == BLU_UNMATCHED_TAXID) ++ht.unmatched;
+            if (r.tax == BLU_UNMATCHED_TAXID) ++c.unmatched;
             r.bs = (int32_t)bs_t; r.aln = (int32_t)aln; r.pid = pid;
-            rows.push_back(r);
-            ++per_query[r.q];
+            c.rows.push_back(r);
         }
-        p = nl ? nl + 1 : end;
+        p = nl ? nl + 1 : c.end;
     }
+    c.n_lines = line_no;
+}
+
+// a2 + a4 + a5: outfmt-6 text -> SoA columns.  The file is cut into line-aligned chunks parsed by worker threads
+// (numbers, tab scanning, the taxid join); dictionaries (queries in first-appearance order, accessions) and the
+// stable grouping are merged in file order afterwards, so the result does not depend on the thread count.
+int load_hits(const char* path, const Db& db, HitTable& ht) {
+    MappedFile f;
+    if (!f.open(path)) { set_error("Unexpected error occurred on load table: %s", path); return BLU_ERR_IO; }
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (const char* env = getenv("BLU_INGEST_THREADS")) nthreads = (unsigned)atoi(env);
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 32) nthreads = 32;
+    if (f.size < (1u << 20)) nthreads = 1;
+    std::vector<Chunk> chunks(nthreads);
+    const char* base = f.data;
+    const char* fend = f.data + f.size;
+    const char* cur = base;
+    for (unsigned t = 0; t < nthreads; ++t) {
+        const char* target = t + 1 == nthreads ? fend : base + (f.size / nthreads) * (t + 1);
+        if (target < cur) target = cur;
+        if (target < fend) {
+            const char* nl = (const char*)memchr(target, '\n', (size_t)(fend - target));
+            target = nl ? nl + 1 : fend;
+        }
+        chunks[t].begin = cur;
+        chunks[t].end = target;
+        cur = target;
+    }
+    if (nthreads == 1) parse_chunk(chunks[0], db, path);
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back([&, t]() { parse_chunk(chunks[t], db, path); });
+        for (auto& th : pool) th.join();
+    }
+    uint64_t lines_before = 0;
+    size_t nh = 0;
+    for (auto& c : chunks) {
+        if (c.rc != BLU_OK) { set_error("%s (chunk starting at line %llu)", c.err.c_str(), (unsigned long long)(lines_before + 1)); return c.rc; }
+        lines_before += c.n_lines;
+        nh += c.rows.size();
+        ht.unmatched += c.unmatched;
+    }
+    // dictionaries, in file order.  Strings keep their quotes stripped (mod.rs:169-172); rows of one query usually
+    // sit next to each other, so the previous row's ids are tried before the hash maps.
+    std::unordered_map<std::string, uint32_t> qids, accids;
+    std::vector<uint32_t> per_query, row_q(nh), row_acc(nh);
+    std::string_view last_q, last_a;
+    uint32_t last_qid = 0, last_aid = 0;
+    bool have_last = false;
+    size_t i = 0;
+    for (auto& c : chunks)
+        for (const RawRow& r : c.rows) {
+            if (!have_last || r.q != last_q) {
+                std::string q = strip_quotes(r.q);
+                auto it = qids.find(q);
+                if (it == qids.end()) { it = qids.emplace(q, (uint32_t)ht.query_names.size()).first; ht.query_names.push_back(std::move(q)); per_query.push_back(0); }
+                last_q = r.q; last_qid = it->second;
+            }
+            if (!have_last || r.acc != last_a) {
+                std::string a = strip_quotes(r.acc);
+                auto it = accids.find(a);
+                if (it == accids.end()) { it = accids.emplace(a, (uint32_t)ht.accessions.size()).first; ht.accessions.push_back(std::move(a)); }
+                last_a = r.acc; last_aid = it->second;
+            }
+            have_last = true;
+            row_q[i] = last_qid; row_acc[i] = last_aid;
+            ++per_query[last_qid];
+            ++i;
+        }
     // order-preserving accession ranks (String::cmp is bytewise)
     std::vector<uint32_t> by_name(ht.accessions.size());
-    for (uint32_t i = 0; i < by_name.size(); ++i) by_name[i] = i;
+    for (uint32_t k = 0; k < by_name.size(); ++k) by_name[k] = k;
     std::sort(by_name.begin(), by_name.end(), [&](uint32_t a, uint32_t b) { return ht.accessions[a] < ht.accessions[b]; });
     std::vector<uint32_t> rank_of(by_name.size());
-    for (uint32_t i = 0; i < by_name.size(); ++i) rank_of[by_name[i]] = i;
+    for (uint32_t k = 0; k < by_name.size(); ++k) rank_of[by_name[k]] = k;
     // stable grouping: queries in first-appearance order, rows of a query in file order (mod.rs:192-208)
-    const size_t nq = ht.query_names.size(), nh = rows.size();
+    const size_t nq = ht.query_names.size();
     ht.seg_off.assign(nq + 1, 0);
     for (size_t q = 0; q < nq; ++q) ht.seg_off[q + 1] = ht.seg_off[q] + per_query[q];
-    std::vector<uint64_t> cur(ht.seg_off.begin(), ht.seg_off.end() - 1);
+    std::vector<uint64_t> at(ht.seg_off.begin(), ht.seg_off.end() - 1);
     ht.bitscore.resize(nh); ht.align_len.resize(nh); ht.tax_desc_row.resize(nh); ht.acc_rank.resize(nh); ht.acc_id.resize(nh); ht.pident.resize(nh);
-    for (const Row& r : rows) {
-        const uint64_t i = cur[r.q]++;
-        ht.bitscore[i] = r.bs; ht.align_len[i] = r.aln; ht.tax_desc_row[i] = r.tax; ht.acc_rank[i] = rank_of[r.acc];
-        ht.acc_id[i] = r.acc; ht.pident[i] = r.pid;
-    }
+    i = 0;
+    for (auto& c : chunks)
+        for (const RawRow& r : c.rows) {
+            const uint64_t d = at[row_q[i]]++;
+            ht.bitscore[d] = r.bs; ht.align_len[d] = r.aln; ht.tax_desc_row[d] = r.tax; ht.acc_rank[d] = rank_of[row_acc[i]];
+            ht.acc_id[d] = row_acc[i]; ht.pident[d] = r.pid;
+            ++i;
+        }
     return BLU_OK;
 }
 
@@ -719,6 +810,34 @@ int blu_build_consensus_identities(const char* blast_output_file, const char* co
 }
 
 void blu_free_text(char* text) { free(text); }
+
+int blu_ingest_only(const char* blast_output_file, const char* taxonomies_file, int use_taxid, blu_pipeline_stats* stats,
+                    uint64_t* checksum) {
+    if (!blast_output_file || !taxonomies_file) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    blu_pipeline_stats st{};
+    double t0 = now_s();
+    Db db;
+    int rc = load_db(taxonomies_file, use_taxid != 0, db);
+    if (rc != BLU_OK) return rc;
+    st.t_load_db_s = now_s() - t0;
+    t0 = now_s();
+    HitTable ht;
+    rc = load_hits(blast_output_file, db, ht);
+    if (rc != BLU_OK) return rc;
+    st.t_load_hits_s = now_s() - t0;
+    st.n_hits = ht.bitscore.size(); st.n_queries = ht.query_names.size(); st.n_taxids = db.taxid.size(); st.n_unmatched_rows = ht.unmatched;
+    if (stats) *stats = st;
+    if (checksum) {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+        mix(ht.seg_off.data(), ht.seg_off.size() * 8); mix(ht.bitscore.data(), ht.bitscore.size() * 4);
+        mix(ht.align_len.data(), ht.align_len.size() * 4); mix(ht.tax_desc_row.data(), ht.tax_desc_row.size() * 4);
+        mix(ht.acc_rank.data(), ht.acc_rank.size() * 4); mix(ht.pident.data(), ht.pident.size() * 8);
+        for (auto& q : ht.query_names) mix(q.data(), q.size() + 1);
+        *checksum = h;
+    }
+    return BLU_OK;
+}
 
 // domain/dtos/taxon.rs:28-66: YAML (flat `key: value` lines) or JSON object with the eight fields
 int blu_custom_taxon_from_file(const char* path, blu_cutoff_config* cfg) {

@@ -39,6 +39,18 @@ def _bind():
     return L
 
 
+def ingest_only(blast_output: str, taxonomies_file: str, use_taxid: bool = False):
+    """Text ingest alone (no GPU): returns (stats, checksum of the SoA columns)."""
+    L = _bind()
+    L.blu_ingest_only.restype = C.c_int
+    L.blu_ingest_only.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(PipelineStats), C.POINTER(C.c_uint64)]
+    st, ck = PipelineStats(), C.c_uint64()
+    rc = L.blu_ingest_only(blast_output.encode(), taxonomies_file.encode(), 1 if use_taxid else 0, C.byref(st), C.byref(ck))
+    if rc != N.BLU_OK:
+        raise N.BluError(rc, "blu_ingest_only")
+    return {f: getattr(st, f) for f, _ in PipelineStats._fields_}, ck.value
+
+
 def custom_taxon_from_file(path: str) -> dict:
     """CustomTaxon::from_file (domain/dtos/taxon.rs:28-66)."""
     cfg = N.CutoffConfig()

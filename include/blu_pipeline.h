@@ -63,6 +63,13 @@ int blu_build_consensus_identities(const char* blast_output_file, const char* co
                                    size_t* out_len, blu_pipeline_stats* stats);
 void blu_free_text(char* text);
 
+/* The text-ingest half alone (no GPU): DB JSON + outfmt-6 TSV -> SoA columns, as blu_build_consensus_identities does it.
+ * Fills stats (rows, queries, taxids, unmatched rows, load times) and *checksum with an FNV-1a hash over every SoA
+ * column, the segment offsets and the query names — identical for any BLU_INGEST_THREADS value.  For tests and for
+ * timing the ingest (rows/s) apart from the engine. */
+int blu_ingest_only(const char* blast_output_file, const char* taxonomies_file, int use_taxid, blu_pipeline_stats* stats,
+                    uint64_t* checksum);
+
 /* CustomTaxon::from_file (domain/dtos/taxon.rs:28-66): .yaml or .json with the eight cutoff fields. */
 int blu_custom_taxon_from_file(const char* path, blu_cutoff_config* cfg);
 
