@@ -23,25 +23,36 @@ struct RankInfo {
 };
 
 // Device view of the taxonomy (passed to kernels by value).
+//
+// Lineage rows sit in LEXICOGRAPHIC order of their node sequences (row index = "pos"; engine row ids are
+// pos | lineage length << BLU_ROW_BITS, so the streaming phase needs no taxonomy lookup).  One row:
+//   word 0      len | shape << 8        (len 0 = lineage that fails parse_taxonomy)
+//   word 1      spare
+//   word 2+2j   node id of level j      interned (Display(rank), identifier)
+//   word 3+2j   cutoff id (12 bits) | canonical rank code (10 bits) << 12 | max-allowed-rank code (10 bits) << 22
+// i.e. everything the finalisation reads about the reference row — identifier, per-level cutoffs, rank codes —
+// in ONE 128-byte line for lineages of up to 15 levels (stride = 32 words; deeper taxonomies use longer rows
+// and only the first line is touched for shallow reference rows).  Cutoffs are stored by id into `cutvals`,
+// the table of the few hundred DISTINCT f64 cutoff values of this (taxonomy, backbone) pair, held in LDS.
 struct TaxDev {
-    // Lineage rows in LEXICOGRAPHIC order of their node sequences (row index = "pos"):
-    // word0 = len | shape << 8 (len 0 = bad lineage), words 1.. = node ids, root -> leaf.
-    const uint32_t* lin;    // [n_tax][stride]
-    // Engine row ids (blu_hits.tax_row) = pos | lineage length << BLU_ROW_BITS (length 0 = bad lineage): the
-    // streaming phase needs no taxonomy lookup at all.  The shape id comes with the reference row's header word.
+    const uint32_t* lin;     // [n_tax][stride]
     // lcp8[i] = number of leading levels shared by sorted rows i and i+1.  In that order the levels shared by a
     // whole group of rows = min(lcp8[lo .. hi-1]) for the group's smallest/largest pos: a range-minimum query
     // replaces the per-row level scan of find_multi_taxa_consensus.rs:137-180.
-    const uint8_t* lcp8;    // [n_tax - 1], padded with 0xFF to a multiple of 16 (+16)
-    const uint8_t* rmq;     // sparse table over 16-entry blocks of lcp8: level k at rmq + k * rmq_nb, entry j = min of blocks j .. j+2^k-1
-    uint32_t rmq_nb;        // blocks per level
-    const double* cut;      // [n_shapes][sc] per-level identity cutoff
-    const uint32_t* codes;  // [n_shapes][sc] rank_code | mar_code << 16
+    const uint8_t* lcp8;     // [n_tax - 1], padded with 0xFF to a multiple of 16 (+16)
+    const uint8_t* rmq;      // sparse table over 16-entry blocks of lcp8: level k at rmq + k * rmq_nb, entry j = min of blocks j .. j+2^k-1
+    uint32_t rmq_nb;         // blocks per level
+    const double* cutvals;   // [n_cutvals] distinct cutoff values (NaN included, compared by bit pattern)
+    uint32_t n_cutvals;
     uint64_t n_tax;
-    uint32_t stride;        // words per lineage row, multiple of 16 (64-byte rows)
-    uint32_t sc;            // entries per shape row
-    uint32_t max_depth;     // longest lineage: bounds the length bits of a (possibly corrupt) row id
+    uint32_t stride;         // words per lineage row, multiple of 32 (128-byte lines)
+    uint32_t max_depth;      // longest lineage: bounds the length bits of a (possibly corrupt) row id
 };
+
+#define BLU_PACK_CUT_BITS 12u
+#define BLU_PACK_CODE_BITS 10u
+#define BLU_PACK_CODE_MASK ((1u << BLU_PACK_CODE_BITS) - 1u)
+#define BLU_PACK_NEVER (BLU_PACK_CODE_MASK - 1u)   // BLU_MAR_NEVER_EQUAL in 10 bits
 
 struct HitsDev {
     const int32_t* bitscore;
@@ -88,8 +99,9 @@ struct blu_taxonomy {
     uint8_t* d_rmq = nullptr;
     uint32_t rmq_nb = 0;
     std::vector<uint32_t> pos_of;            // caller's tax_row -> sorted position
-    double* d_cut = nullptr;
-    uint32_t* d_codes = nullptr;
+    double* d_cutvals = nullptr;
+    uint32_t n_cutvals = 0;
+    uint32_t dev_stride = 32;                // words per DEVICE row (interleaved layout); `stride` is the host layout's
     uint64_t device_bytes = 0;
     // per-handle scratch of the run call (worklist of long / overflowing queries); grown on demand,
     // so one handle must not be used by two concurrent blu_consensus_run calls

@@ -138,6 +138,13 @@ __device__ __forceinline__ void store_status(blu_result* out, uint64_t q, uint32
     store_result(out, q, status, 0, BLU_NONE_U8, BLU_NONE_U8, BLU_NONE_U16, BLU_NONE_U16, 0xFFFFFFFFu, ref_row, 0ull, 0.0);
 }
 
+// packed level word of a lineage row -> the ABI's 16-bit rank codes
+__device__ __forceinline__ uint32_t packed_rank(uint32_t p) { return (p >> BLU_PACK_CUT_BITS) & BLU_PACK_CODE_MASK; }
+__device__ __forceinline__ uint32_t packed_mar(uint32_t p) {
+    const uint32_t m = p >> (BLU_PACK_CUT_BITS + BLU_PACK_CODE_BITS);
+    return m == BLU_PACK_NEVER ? BLU_MAR_NEVER_EQUAL : m;
+}
+
 // Stable sort by (len, pident, align_len, accession), then .first() (Cautious) or
 // .last() (Relaxed): find_multi_taxa_consensus.rs:39-68.  Candidates arrive in file
 // order, so Relaxed replaces the incumbent on ties (>=), Cautious keeps it (<).
@@ -199,6 +206,7 @@ struct Entry {            // one top-group row in LDS, 24 bytes
 static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 
 #define META_SLOW 0x80000000u
+#define CUT_LDS 512        // distinct cutoff values kept in LDS (4 KiB); larger tables are read from global memory
 #define ROW_MASK ((1u << BLU_ROW_BITS) - 1u)
 // the five hit columns are read exactly once per run: non-temporal loads keep them from displacing the
 // lineage rows and cutoff tables (re-read by every query) in L2 / Infinity Cache
@@ -230,6 +238,13 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                                                                        uint32_t* __restrict__ worklist,
                                                                        uint32_t* __restrict__ work_count) {
     __shared__ WaveLds s_lds[WAVES_A];
+    // the distinct cutoff values of this (taxonomy, backbone): a few hundred doubles, read per level in phase 2c
+    __shared__ double s_cut[CUT_LDS];
+    const bool cut_in_lds = t.n_cutvals <= CUT_LDS;
+    if (cut_in_lds) {
+        for (uint32_t i = threadIdx.x; i < t.n_cutvals; i += BLOCK_A) s_cut[i] = t.cutvals[i];
+        __syncthreads();
+    }
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     WaveLds& L = s_lds[wib];
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                         r_pos = take ? (x.pq & 0xFF) : r_pos;
                     }
                     mode = k == 1 ? 2u : 0u;
-#ifndef BLU_EXP_LATE_HDR
+#ifdef BLU_EXP_EARLY_HDR
                     // start the reference row's fetch now (header word = shape id; the identifier sits in the same
                     // 64-byte row): it overlaps the range-minimum lookups below instead of following them
                     r_hdr = t.lin[(uint64_t)r_row * t.stride];
@@ -453,58 +468,70 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             rec_kind = 1;
             if (!agree && d == 0) pack_status(ra, rb, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
             else {
-                // the reference row's header word gives the shape; the identifier read below hits the same 64-byte row
+                // One 128-byte line of the reference row holds its node ids, per-level cutoff ids and rank codes
+                // (interleaved: word 2+2j = node, word 3+2j = cutoff id | rank code << 12 | max-allowed code << 22).
 #ifdef BLU_EXP_NOREF
                 const uint32_t* ref = t.lin;
 #else
                 const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
 #endif
-#ifdef BLU_EXP_LATE_HDR
-                r_hdr = ref[0];
+#ifndef BLU_EXP_EARLY_HDR
+                r_hdr = ref[0];   // (requesting it back in phase 2a costs a second fetch: the line leaves L2 in between)
 #endif
-                const uint32_t len_ref = r_len, shape = r_hdr >> 8;
+                // (the header word was requested in phase 2a, so the row's line is on its way; its length field equals
+                // the id's for a well-formed id and bounds the loop for a corrupt one)
+                const uint32_t len_ref = umin(r_len, r_hdr & 0xFF);
                 const uint32_t b = single ? len_ref : (agree ? minlen - 1 : d - 1);
                 const double ident = (single | agree) ? r_pid : max_pid;
-                const double* cut = t.cut + (uint64_t)shape * t.sc;
-                const uint32_t* codes = t.codes + (uint64_t)shape * t.sc;
+                const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
                 // linnaean_ranks.rs:174-212 + build_blast_consensus_identity.rs:67-82
                 uint64_t F = 0, A = 0;
                 uint32_t mar_level = BLU_NONE_U8, nF = 0;
-                for (uint32_t j0 = 0; j0 < len_ref; j0 += 8) {   // cutoff rows are padded to a multiple of 16 entries
-                    double2 cc[4];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) cc[v] = *reinterpret_cast<const double2*>(cut + j0 + 2 * v);
-#pragma unroll
-                    for (int v = 0; v < 8; ++v) {
-                        const uint32_t j = j0 + v;
-                        const double cj = (v & 1) ? cc[v >> 1].y : cc[v >> 1].x;
-                        if (j < len_ref) {
-                            if (mar_level == BLU_NONE_U8 && !(ident > cj)) mar_level = j;   // skip_while(identity > cutoff)
-                            if (ident >= cj) {                                             // filter(identity >= cutoff)
-                                F |= 1ull << j;
-                                if (nF <= b) A |= 1ull << j;                               // first (b + 1) elements of the filtered list
-                                ++nF;
-                            }
+                auto level = [&](uint32_t j, uint32_t packed) {
+                    if (j < len_ref) {
+                        const uint32_t cid = packed & ((1u << BLU_PACK_CUT_BITS) - 1u);
+                        const double cj = cut_in_lds ? s_cut[cid] : t.cutvals[cid];
+                        if (mar_level == BLU_NONE_U8 && !(ident > cj)) mar_level = j;   // skip_while(identity > cutoff)
+                        if (ident >= cj) {                                             // filter(identity >= cutoff)
+                            F |= 1ull << j;
+                            if (nF <= b) A |= 1ull << j;                               // first (b + 1) elements of the filtered list
+                            ++nF;
                         }
                     }
+                };
+                // chunk 0 = {header, spare, node 0, packed 0}; chunk k >= 1 = levels 2k-1 and 2k.  The first line of
+                // the row (levels 0..14) is read with eight loads issued back to back: the line is requested from
+                // memory once, instead of once per loop iteration after the stream has pushed it out of L2 again.
+                {
+                    uint4 w[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) w[k] = ref4[k];
+                    level(0, w[0].w);
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) { level(2 * k - 1, w[k].y); level(2 * k, w[k].w); }
+                }
+                for (uint32_t k = 8; 2 * k - 1 < len_ref; ++k) {   // lineages deeper than 15 levels
+                    const uint4 x = ref4[k];
+                    level(2 * k - 1, x.y);
+                    level(2 * k, x.w);
                 }
                 if (agree) A = F;                                                  // single hit / single-flag branch (:74-75)
                 if (single) {
                     if (!A) pack_status(ra, rb, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, row0 + r_pos);   // find_single_query_consensus.rs:113-119
                     else {
                         const uint32_t last = (uint32_t)last_lane(A);
-                        pack_result(ra, rb, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, codes[last] & 0xFFFF, BLU_NONE_U16,
-                                     ref[1 + last], row0 + r_pos, A, ident);
+                        pack_result(ra, rb, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, packed_rank(ref[3 + 2 * last]), BLU_NONE_U16,
+                                     ref[2 + 2 * last], row0 + r_pos, A, ident);
                     }
                 } else {
                     const uint32_t last = A ? (uint32_t)last_lane(A) : b;          // .last().unwrap_or(taxonomy[bean_index])
                     uint32_t flags = agree ? BLU_FLAG_AGREE : 0u, mar_code = BLU_NONE_U16;
                     if (mar_level != BLU_NONE_U8) {
-                        mar_code = codes[mar_level] >> 16;
-                        if (mar_code != (codes[b] & 0xFFFF)) flags |= BLU_FLAG_MUTATED;   // bean.reached_rank != allowed_rank (:35-37)
+                        mar_code = packed_mar(ref[3 + 2 * mar_level]);
+                        if (mar_code != packed_rank(ref[3 + 2 * b])) flags |= BLU_FLAG_MUTATED;   // bean.reached_rank != allowed_rank (:35-37)
                     }
-                    pack_result(ra, rb, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, codes[last] & 0xFFFF, mar_code,
-                                 ref[1 + last], row0 + r_pos, A, ident);
+                    pack_result(ra, rb, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, packed_rank(ref[3 + 2 * last]), mar_code,
+                                 ref[2 + 2 * last], row0 + r_pos, A, ident);
                 }
             }
         }
@@ -714,14 +741,15 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
         }
         const uint32_t row_ref = (uint32_t)rl((int)b_row, rlane);
         const uint32_t len_ref = (uint32_t)rl((int)b_len, rlane);
-        const uint32_t shape_ref = t.lin[(uint64_t)row_ref * t.stride] >> 8;
+
         const uint32_t pos_ref = (uint32_t)rl((int)b_pos, rlane);
         const double pid_ref = rl_f64(b_pid, rlane);
         const bool in_l = (uint32_t)lane < len_ref;
         const uint32_t lvl = in_l ? (uint32_t)lane : 0u;
-        const uint32_t ref_node = t.lin[(uint64_t)row_ref * t.stride + 1 + lvl];
-        const double cut = t.cut[(uint64_t)shape_ref * t.sc + lvl];
-        const uint32_t codes = t.codes[(uint64_t)shape_ref * t.sc + lvl];
+        const uint32_t ref_node = t.lin[(uint64_t)row_ref * t.stride + 2 + 2 * lvl];
+        const uint32_t packed = t.lin[(uint64_t)row_ref * t.stride + 3 + 2 * lvl];
+        const double cut = t.cutvals[packed & ((1u << BLU_PACK_CUT_BITS) - 1u)];
+        const uint32_t codes = packed_rank(packed) | (packed_mar(packed) << 16);
         const uint32_t ref_row = (uint32_t)start + pos_ref;
         if (k == 1) {   // find_single_query_consensus.rs:74-150
             const uint64_t A = __ballot(in_l && pid_ref >= cut);

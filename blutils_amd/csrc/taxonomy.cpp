@@ -281,9 +281,41 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
     tax->pos_of.assign(n, 0);
     for (uint64_t i = 0; i < n; ++i)   // engine row id: sorted position | lineage length << BLU_ROW_BITS
         tax->pos_of[order[i]] = (uint32_t)i | ((L[(size_t)order[i] * stride] & 0xFF) << BLU_ROW_BITS);
-    std::vector<uint32_t> lin_sorted((size_t)n * stride);
+    std::vector<uint32_t> lin_sorted((size_t)n * stride);   // host layout (hdr, nodes), sorted: for the LCP pass below
     for (uint64_t i = 0; i < n; ++i)
         memcpy(&lin_sorted[(size_t)i * stride], L + (size_t)order[i] * stride, stride * sizeof(uint32_t));
+    // distinct cutoff values (by bit pattern, NaN included) and the device rows (interleaved node / packed level words)
+    if (tax->ranks.size() > BLU_PACK_NEVER) { delete tax; set_error("more than %u distinct rank names", BLU_PACK_NEVER); return BLU_ERR_INVALID_ARG; }
+    std::map<uint64_t, uint32_t> cut_ids;
+    std::vector<double> cutvals;
+    auto cut_id = [&](double v) {
+        uint64_t bits;
+        memcpy(&bits, &v, 8);
+        auto it = cut_ids.find(bits);
+        if (it == cut_ids.end()) { it = cut_ids.emplace(bits, (uint32_t)cutvals.size()).first; cutvals.push_back(v); }
+        return it->second;
+    };
+    const uint32_t dstride = ((2 + 2 * std::max<uint32_t>(tax->max_depth, 1) + 31) / 32) * 32;
+    tax->dev_stride = dstride;
+    std::vector<uint32_t> dev_rows(std::max<size_t>((size_t)n * dstride, 32), 0u);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t* src = &lin_sorted[(size_t)i * stride];
+        uint32_t* dst = &dev_rows[(size_t)i * dstride];
+        const uint32_t len = src[0] & 0xFF, shape = src[0] >> 8;
+        dst[0] = src[0];
+        for (uint32_t j = 0; j < len; ++j) {
+            const size_t k = (size_t)shape * tax->sc + j;
+            const uint32_t code = tax->h_codes[k];
+            const uint32_t rank = code & 0xFFFF, mar = code >> 16;
+            const uint32_t cid = cut_id(tax->h_cut[k]);
+            dst[2 + 2 * j] = src[1 + j];
+            dst[3 + 2 * j] = cid | (rank << BLU_PACK_CUT_BITS) |
+                             ((mar == BLU_MAR_NEVER_EQUAL ? BLU_PACK_NEVER : mar) << (BLU_PACK_CUT_BITS + BLU_PACK_CODE_BITS));
+        }
+    }
+    if (cutvals.size() >= (1u << BLU_PACK_CUT_BITS)) { delete tax; set_error("more than %u distinct cutoff values", (1u << BLU_PACK_CUT_BITS) - 1); return BLU_ERR_INVALID_ARG; }
+    if (cutvals.empty()) cutvals.push_back(0.0);
+    tax->n_cutvals = (uint32_t)cutvals.size();
     tax->order = order;
     const uint64_t n_lcp = n > 0 ? n - 1 : 0;
     const uint32_t nb = (uint32_t)((n_lcp + 15) / 16) + 1;            // 16-entry blocks (+1 block of padding)
@@ -319,25 +351,22 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         hipDeviceProp_t prop;
         if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
         if (e == hipSuccess) tax->num_cus = prop.multiProcessorCount;
-        size_t b_lin = std::max<size_t>(lin_sorted.size(), 16) * sizeof(uint32_t);
-        size_t b_cut = tax->h_cut.size() * sizeof(double);
-        size_t b_codes = tax->h_codes.size() * sizeof(uint32_t);
+        size_t b_lin = dev_rows.size() * sizeof(uint32_t);
+        size_t b_cut = cutvals.size() * sizeof(double);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lin, b_lin);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lcp8, lcp8.size());
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_rmq, rmq.size());
-        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_cut, b_cut);
-        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_codes, b_codes);
-        if (e == hipSuccess && !lin_sorted.empty()) e = hipMemcpy(tax->d_lin, lin_sorted.data(), lin_sorted.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_cutvals, b_cut);
+        if (e == hipSuccess) e = hipMemcpy(tax->d_lin, dev_rows.data(), b_lin, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_lcp8, lcp8.data(), lcp8.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_rmq, rmq.data(), rmq.size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(tax->d_cut, tax->h_cut.data(), b_cut, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(tax->d_codes, tax->h_codes.data(), b_codes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(tax->d_cutvals, cutvals.data(), b_cut, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             set_error("HIP error while uploading the taxonomy: %s", hipGetErrorString(e));
             blu_taxonomy_destroy(tax);
             return BLU_ERR_HIP;
         }
-        tax->device_bytes = b_lin + lcp8.size() + rmq.size() + b_cut + b_codes;
+        tax->device_bytes = b_lin + lcp8.size() + rmq.size() + b_cut;
     }
     *out = tax;
     return BLU_OK;
@@ -350,8 +379,7 @@ void blu_taxonomy_destroy(blu_taxonomy* tax) {
         if (tax->d_lin) (void)hipFree(tax->d_lin);
         if (tax->d_lcp8) (void)hipFree(tax->d_lcp8);
         if (tax->d_rmq) (void)hipFree(tax->d_rmq);
-        if (tax->d_cut) (void)hipFree(tax->d_cut);
-        if (tax->d_codes) (void)hipFree(tax->d_codes);
+        if (tax->d_cutvals) (void)hipFree(tax->d_cutvals);
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
         if (tax->ws_count) (void)hipFree(tax->ws_count);
     }
