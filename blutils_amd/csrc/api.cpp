@@ -40,7 +40,10 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     if (tax->ws_capacity < hits->n_queries || !tax->ws_count) {
         // grows only when a larger table than any before arrives (first call): not graph-capturable
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
-        if (!tax->ws_count && hipMalloc((void**)&tax->ws_count, 256) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return BLU_ERR_ALLOC; }
+        if (!tax->ws_count) {
+            if (hipMalloc((void**)&tax->ws_count, 256) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return BLU_ERR_ALLOC; }
+            if (hipMemset(tax->ws_count, 0, 256) != hipSuccess) { set_error("hipMemset(workspace) failed"); return BLU_ERR_HIP; }
+        }
         tax->ws_worklist = nullptr;
         tax->ws_capacity = 0;
         if (hipMalloc((void**)&tax->ws_worklist, (hits->n_queries + 64) * sizeof(uint32_t)) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return BLU_ERR_ALLOC; }
@@ -49,7 +52,10 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     if (hits->on_device) {
         HitsDev hd{hits->bitscore, hits->tax_row, hits->pident, hits->align_len, hits->acc_rank, hits->seg_off,
                    hits->n_hits, hits->n_queries};
-        return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count);
+        uint32_t* cur = tax->ws_count + tax->ws_parity;
+        uint32_t* nxt = tax->ws_count + (tax->ws_parity ^ 1u);
+        tax->ws_parity ^= 1u;
+        return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus, tax->ws_worklist, cur, nxt);
     }
 
     // host pointers: stage over PCIe, run, copy the records back (synchronous)
@@ -76,7 +82,12 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         HIP_TRY(hipMemcpyAsync(d_seg, hits->seg_off, (nq + 1) * 8, hipMemcpyHostToDevice, s));
         HitsDev hd{(const int32_t*)d_bs, (const uint32_t*)d_tax, (const double*)d_pid, (const int32_t*)d_aln,
                    (const uint32_t*)d_acc, (const uint64_t*)d_seg, hits->n_hits, hits->n_queries};
-        rc = launch_consensus(td, hd, params->strategy, (blu_result*)d_out, s, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count);
+        {
+            uint32_t* cur = tax->ws_count + tax->ws_parity;
+            uint32_t* nxt = tax->ws_count + (tax->ws_parity ^ 1u);
+            tax->ws_parity ^= 1u;
+            rc = launch_consensus(td, hd, params->strategy, (blu_result*)d_out, s, tax->device, tax->num_cus, tax->ws_worklist, cur, nxt);
+        }
         if (rc != BLU_OK) goto done;
         HIP_TRY(hipMemcpyAsync(out, d_out, nq * sizeof(blu_result), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));

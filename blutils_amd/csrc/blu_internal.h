@@ -66,9 +66,9 @@ struct HitsDev {
 };
 
 // launch wrapper implemented in consensus_kernel.hip
-// worklist: n_queries uint32 slots; work_count: one uint32 (both device memory)
+// worklist: n_queries uint32 slots; work_count / next_count: this run's (already zero) and the next run's counter
 int launch_consensus(const TaxDev& tax, const HitsDev& hits, int strategy, blu_result* out, void* stream,
-                     int device, int num_cus, uint32_t* worklist, uint32_t* work_count);
+                     int device, int num_cus, uint32_t* worklist, uint32_t* work_count, uint32_t* next_count);
 const char* consensus_kernel_name();
 void consensus_last_geometry(uint32_t* grid, uint32_t* block);
 
@@ -108,4 +108,5 @@ struct blu_taxonomy {
     mutable uint32_t* ws_worklist = nullptr;
     mutable uint32_t* ws_count = nullptr;
     mutable uint64_t ws_capacity = 0;
+    mutable uint32_t ws_parity = 0;           // which of the two worklist counters the next run uses
 };

@@ -236,7 +236,11 @@ struct WaveLds {
 template <int STRAT>
 __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                        uint32_t* __restrict__ worklist,
-                                                                       uint32_t* __restrict__ work_count) {
+                                                                       uint32_t* __restrict__ work_count,
+                                                                       uint32_t* __restrict__ next_count) {
+    // two worklist counters, used alternately by consecutive runs on a handle: this run's is zero already (the
+    // previous run cleared it here), the other one is cleared now for the next run — no memset on the stream
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0u;
     __shared__ WaveLds s_lds[WAVES_A];
     // the distinct cutoff values of this (taxonomy, backbone): a few hundred doubles, read per level in phase 2c
     __shared__ double s_cut[CUT_LDS];
@@ -804,7 +808,7 @@ void consensus_last_geometry(uint32_t* grid, uint32_t* block) {
 
 template <int STRAT>
 static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hipStream_t s, int num_cus,
-                    uint32_t* worklist, uint32_t* work_count) {
+                    uint32_t* worklist, uint32_t* work_count, uint32_t* next_count) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blu_consensus_stream_kernel<STRAT>, BLOCK_A, 0) != hipSuccess || per_cu <= 0)
         per_cu = 2;
@@ -815,22 +819,20 @@ static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hip
     if (grid == 0) grid = 1;
     g_grid = grid;
     g_block = BLOCK_A;
-    hipError_t e = hipMemsetAsync(work_count, 0, sizeof(uint32_t), s);
-    if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
-    hipLaunchKernelGGL(blu_consensus_stream_kernel<STRAT>, dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count);
+    hipLaunchKernelGGL(blu_consensus_stream_kernel<STRAT>, dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count, next_count);
     const uint32_t grid_b = (uint32_t)(num_cus > 0 ? num_cus : 256) * 4u;
     hipLaunchKernelGGL(blu_consensus_long_kernel<STRAT>, dim3(grid_b), dim3(256), 0, s, hits, tax, out, worklist, work_count);
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("kernel launch failed: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
     return BLU_OK;
 }
 
 int launch_consensus(const TaxDev& tax, const HitsDev& hits, int strategy, blu_result* out, void* stream, int device,
-                     int num_cus, uint32_t* worklist, uint32_t* work_count) {
+                     int num_cus, uint32_t* worklist, uint32_t* work_count, uint32_t* next_count) {
     (void)device;
     if (hits.n_queries == 0) return BLU_OK;
-    if (strategy == BLU_RELAXED) return launch_t<BLU_RELAXED>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count);
-    return launch_t<BLU_CAUTIOUS>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count);
+    if (strategy == BLU_RELAXED) return launch_t<BLU_RELAXED>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count, next_count);
+    return launch_t<BLU_CAUTIOUS>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count, next_count);
 }
 
 }  // namespace blu

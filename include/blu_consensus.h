@@ -180,7 +180,9 @@ int blu_taxonomy_row_map(const blu_taxonomy* tax, uint32_t* out_map, uint32_t* o
 
 /* The hot path: one blu_result per query.  `out` has n_queries records, on the
  * device when hits->on_device, else on the host.  Asynchronous on
- * params->stream when on_device (no host sync inside); synchronous otherwise. */
+ * params->stream when on_device (no host sync inside); synchronous otherwise.
+ * Consecutive runs on one handle must be ordered (same stream, or synchronised): the handle's scratch
+ * (worklist, alternating counters) is reused from run to run. */
 int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_run_params* params,
                       blu_result* out);
 
