@@ -13,7 +13,7 @@ nbytes = 24 * H
 s = torch.cuda.current_stream().cuda_stream
 import itertools
 outp = torch.zeros(n_seg * 8 + (1 << 24), dtype=torch.int32, device='cuda')
-for (W, U), lds, sm in itertools.product(((4, 1),), (26624,), (0, 18, 7, 8, 0, 18, 7, 8)):
+for (W, U), lds, sm in itertools.product(((4, 1), (5, 1), (5, 2), (5, 4)), (0,), (0, 18)):
     for grid in (2048,):
         args = [c.data_ptr() for c in cols] + [n_seg, seg, sink.data_ptr(), grid, U, W, s, lds, outp.data_ptr(), sm]
         for _ in range(2):

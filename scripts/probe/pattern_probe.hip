@@ -32,6 +32,34 @@ __global__ __launch_bounds__(256) void pattern_kernel(const int* __restrict__ c0
 #pragma unroll
                 for (int u = 0; u < U; ++u) acc ^= a[u] ^ b[u] ^ d[u] ^ e[u] ^ (uint32_t)__double2loint(c[u]);
             }
+        } else if (W == 5) {
+            typedef int i4 __attribute__((ext_vector_type(4), aligned(4)));
+            const int g = lane >> 4, sub = lane & 15;
+            for (int q = 0; q < 64; q += 4 * U) {
+                i4 a[U];
+                uint64_t row[U];
+                int top0[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint64_t segi = task * 64 + q + 4 * u + g;
+                    row[u] = base + (uint64_t)(q + 4 * u + g) * seg + 4 * sub;
+                    a[u] = 0;
+                    if (4 * sub < seg) a[u] = *(const i4*)(c0 + row[u]);
+                    top0[u] = (int)((segi * 2654435761ull) % (uint64_t)(seg - 3));   // rows top0..top0+2 are the top group
+                }
+                int x[U]; double y[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    x[u] = a[u].x ^ a[u].y ^ a[u].z ^ a[u].w; y[u] = 0;   // consumes the bitscores first (dependent phase)
+                    const int bias = (x[u] == 0x7fffffff) ? 1 : 0;
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = 4 * sub + r;
+                        if (rr >= top0[u] + bias && rr < top0[u] + 3 && rr < seg) { x[u] ^= c1[row[u] + r] ^ c3[row[u] + r] ^ c4[row[u] + r]; y[u] += c2[row[u] + r]; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc ^= x[u] ^ (uint32_t)__double2loint(y[u]);
+            }
         } else {
             // 4 segments per wave instruction: 16 lanes x 4 consecutive rows
             typedef int i4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -103,6 +131,7 @@ __global__ __launch_bounds__(256) void pattern_kernel(const int* __restrict__ c0
 extern "C" int pattern_run(const void* c0, const void* c1, const void* c2, const void* c3, const void* c4, uint64_t n_seg,
                            int seg, void* sink, int grid, int U, int W, void* stream, int lds_bytes, void* outp, int store_mode) {
     if (W == 1) { if (U == 2) LAUNCH(2, 1); else if (U == 4) LAUNCH(4, 1); else if (U == 8) LAUNCH(8, 1); else LAUNCH(16, 1); }
+    else if (W == 5) { if (U == 1) LAUNCH(1, 5); else if (U == 2) LAUNCH(2, 5); else LAUNCH(4, 5); }
     else { if (U == 1) LAUNCH(1, 4); else if (U == 2) LAUNCH(2, 4); else LAUNCH(4, 4); }
     return (int)hipGetLastError();
 }

@@ -117,3 +117,43 @@ def oracle_rank_tables(tax: synth.SynthTaxonomy, taxon, custom):
         return bool(cache[key][level])
 
     return disp.__getitem__, serde.__getitem__, is_default
+
+
+def adversarial_case(seed, n_tax=40, n_q=3000, max_hits=7):
+    """Tiny hand-rolled taxonomy and hit table built to collide on every sort key: few distinct pident /
+    align_len / accession values, two bit-score values, lineages that are prefixes of each other, duplicate
+    lineages under different taxids, non-default ranks in odd places, segments of 1..max_hits rows."""
+    rng = np.random.default_rng(seed)
+    rank_names = ["d", "k", "p", "c", "o", "f", "g", "s", "clade", "no rank", "strain", "u", "Domain"]
+    pool = [["d", "p", "c", "o", "f", "g", "s"], ["d", "clade", "p", "c", "o", "f", "g", "s"], ["d", "p", "c", "o", "f", "g"],
+            ["d", "p", "c", "o", "f", "g", "s", "strain"], ["Domain", "k", "p", "c"], ["d", "p", "c", "o", "f", "no rank", "g", "s"],
+            ["d"], ["d", "p"], ["u", "d", "p", "c", "o"], ["d", "p", "clade", "clade", "c"]]
+    off, node, rank = [0], [], []
+    for t in range(n_tax):
+        ranks = pool[int(rng.integers(0, len(pool)))]
+        k = int(rng.integers(1, len(ranks) + 1)) if rng.random() < 0.3 else len(ranks)
+        parent_choice = int(rng.integers(0, 3))
+        for j in range(k):
+            # few distinct nodes per level so that lineages share long prefixes; level 0 mostly the same node
+            width = 1 if j == 0 and rng.random() < 0.9 else min(1 + j // 2, 3)
+            node.append(1000 * j + (parent_choice if j < 3 else int(rng.integers(0, width))))
+            rank.append(rank_names.index(ranks[j]))
+        off.append(len(node))
+    # the ABI wants node ids interned on (Display(rank), identifier): the same identifier under two different
+    # canonical ranks is two nodes ("d" and "Domain" are one rank, "u" is another)
+    interned = {}
+    node = [interned.setdefault((orc.rank_display(rank_names[r]), n), len(interned)) for n, r in zip(node, rank)]
+    tax = synth.SynthTaxonomy(rank_names, np.array(off, np.uint64), np.array(node, np.uint32), np.array(rank, np.uint16),
+                              (100 + np.arange(n_tax)).astype(np.int64), np.zeros((9, n_tax), np.int32), np.zeros((9, n_tax), np.int32),
+                              n_tax, seed, False)
+    lens = rng.integers(1, max_hits + 1, n_q)
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    H = int(seg[-1])
+    hits = {"seg_off": seg,
+            "bitscore": rng.choice([500, 500, 500, 499], H).astype(np.int32),
+            "tax_row": rng.integers(0, n_tax, H).astype(np.int32),
+            "pident": rng.choice([97.0, 97.0, 99.0, 60.0, 85.0, 45.5], H).astype(np.float64),
+            "align_len": rng.choice([400, 400, 401], H).astype(np.int32),
+            "acc_rank": rng.integers(0, 4, H).astype(np.int32)}
+    hits["tax_row"][rng.random(H) < 0.01] = -1
+    return tax, hits

@@ -132,6 +132,23 @@ def test_error_statuses_and_edge_segments():
     assert set(got["status"].tolist()) <= {N.ST_NO_HITS, 16, 17, N.ST_ERR_BAD_PIDENT}
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_adversarial_ties_and_prefix_lineages(seed):
+    """Tiny tables built to collide on every sort key (see helpers.adversarial_case): the engine against both
+    oracles, both strategies, built-in and custom backbones, bad lineages included."""
+    tax, hits = H.adversarial_case(seed, n_q=5000)
+    bad = (np.arange(tax.n) % 17 == 3).astype(np.uint8)
+    for taxon, custom in (("bacteria", None), ("custom", H.CUSTOM_16S), ("fungi", None)):
+        t = _engine_tax(tax, taxon, custom, bad=bad)
+        for strategy in ("relaxed", "cautious"):
+            got = _run_host(t, hits, strategy)
+            _assert_records_equal(got, H.columnar(tax, hits, taxon, strategy, custom, bad=bad))
+    faithful = orc.run(H.oracle_table(tax, hits, bad), taxon="fungi", strategy="cautious", threads=4).results()
+    r = _engine_renderer(t, tax, hits)
+    for q in range(len(got)):
+        H.assert_matches_faithful(r.render(got[q]), faithful[q], q)
+
+
 def _intern_lineages(lineages):
     """lineage strings -> CSR over interned canonical (rank, identifier) pairs."""
     ranks, rank_id, nodes = [], {}, {}

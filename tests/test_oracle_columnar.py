@@ -42,3 +42,14 @@ def test_columnar_vs_faithful_bad_lineages_and_errors():
     recs = _check(tax, hits, "bacteria", "relaxed", bad=bad)
     st = set(recs["status"].tolist())
     assert {16, 17, 18}.issubset(st), st                          # unmatched, bad lineage, root disagreement
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("strategy", ["relaxed", "cautious"])
+def test_columnar_vs_faithful_adversarial_ties(seed, strategy):
+    """Collisions on every sort key, prefix lineages, duplicate lineages, odd rank sequences."""
+    tax, hits = H.adversarial_case(seed)
+    bad = (np.arange(tax.n) % 17 == 3).astype(np.uint8)
+    for taxon, custom in (("bacteria", None), ("custom", H.CUSTOM_16S)):
+        recs = _check(tax, hits, taxon, strategy, custom, bad)
+    assert len(set(recs["status"].tolist())) >= 5
