@@ -776,23 +776,42 @@ int blu_build_consensus_identities(const char* blast_output_file, const char* co
         }
         o += "config: null\n";
     }
-    bool first = true;
-    if (params->out_format != BLU_OUT_YAML)
-    for (const Item& it : items) {
-        const int ind = pretty ? 2 : 0;
-        auto nl = [&](int extra) { if (pretty) { o.push_back('\n'); o.append((size_t)(ind + extra) * 2, ' '); } };
-        const char* colon = pretty ? ": " : ":";
-        if (pretty) { if (!first) o.push_back(','); nl(0); }
-        else if (doc && !first) o.push_back(',');
-        first = false;
-        o.push_back('{');
-        nl(1); o += "\"runId\""; o += colon; json_str(o, run_id);
-        o.push_back(','); nl(1); o += "\"query\""; o += colon; json_str(o, *it.name);
-        o.push_back(','); nl(1); o += "\"taxon\""; o += colon;
-        if (it.q < 0 || recs[(size_t)it.q].status >= 2) o += "null";
-        else R.taxon(o, (uint64_t)it.q, recs[(size_t)it.q], pretty, ind + 1);
-        nl(0); o.push_back('}');
-        if (!doc) o.push_back('\n');
+    if (params->out_format != BLU_OUT_YAML) {
+        // records are independent: slices of the sorted list are rendered by worker threads and concatenated in order
+        unsigned nthreads = std::thread::hardware_concurrency();
+        if (const char* env = getenv("BLU_INGEST_THREADS")) nthreads = (unsigned)atoi(env);
+        if (nthreads < 1) nthreads = 1;
+        if (nthreads > 32) nthreads = 32;
+        if (items.size() < 4096) nthreads = 1;
+        std::vector<std::string> parts(nthreads);
+        auto render_slice = [&](unsigned ti) {
+            std::string& po = parts[ti];
+            const size_t i0 = items.size() * ti / nthreads, i1 = items.size() * (ti + 1) / nthreads;
+            po.reserve((i1 - i0) * 640);
+            for (size_t ii = i0; ii < i1; ++ii) {
+                const Item& it = items[ii];
+                const int ind = pretty ? 2 : 0;
+                auto nl = [&](int extra) { if (pretty) { po.push_back('\n'); po.append((size_t)(ind + extra) * 2, ' '); } };
+                const char* colon = pretty ? ": " : ":";
+                if (pretty) { if (ii) po.push_back(','); nl(0); }
+                else if (doc && ii) po.push_back(',');
+                po.push_back('{');
+                nl(1); po += "\"runId\""; po += colon; json_str(po, run_id);
+                po.push_back(','); nl(1); po += "\"query\""; po += colon; json_str(po, *it.name);
+                po.push_back(','); nl(1); po += "\"taxon\""; po += colon;
+                if (it.q < 0 || recs[(size_t)it.q].status >= 2) po += "null";
+                else R.taxon(po, (uint64_t)it.q, recs[(size_t)it.q], pretty, ind + 1);
+                nl(0); po.push_back('}');
+                if (!doc) po.push_back('\n');
+            }
+        };
+        if (nthreads == 1) render_slice(0);
+        else {
+            std::vector<std::thread> pool;
+            for (unsigned ti = 0; ti < nthreads; ++ti) pool.emplace_back(render_slice, ti);
+            for (auto& th : pool) th.join();
+        }
+        for (auto& po : parts) o += po;
     }
     if (params->out_format == BLU_OUT_YAML) {}
     else if (pretty) { if (!items.empty()) o += "\n  "; o += "],\n  \"config\": null\n}"; }
