@@ -160,3 +160,24 @@ def test_cli_and_yaml(tmp_path, capsys):
     assert jl[0] == "null" and strip([json.loads(l) for l in jl[1:]]) == strip(doc["results"])
     with pytest.raises(SystemExit):
         cli.main(["blastn", "build-consensus", bt, "-t", tj, "--taxon", "custom", "--strategy", "relaxed"])
+
+
+def test_parallel_ingest_and_render_are_deterministic(tmp_path):
+    """>= 4096 queries and > 1 MiB of text take the multi-threaded ingest and render paths: same document as
+    the single-threaded run (runId aside)."""
+    import re
+    tax = synth.make_taxonomy(1500, 8)
+    hits = synth.make_hits(tax, 6000, 9, 12, p_unmatched=0.001).numpy()
+    bt, tj, _ = _write_inputs(tmp_path, tax, hits, scramble=True)
+    assert os.path.getsize(bt) > (1 << 20)
+    docs = []
+    for threads in ("1", "7"):
+        os.environ["BLU_INGEST_THREADS"] = threads
+        try:
+            raw, st = pipeline.build_consensus_identities(bt, tj, "bacteria", "relaxed", lenient=True, parse=False)
+        finally:
+            os.environ.pop("BLU_INGEST_THREADS", None)
+        assert st["n_queries"] == 6000
+        docs.append(re.sub(r'"runId": "[0-9a-f-]+"', '"runId": "x"', raw))
+    assert docs[0] == docs[1]
+    assert len(json.loads(docs[0])["results"]) == 6000
