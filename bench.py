@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--strategy", default="relaxed", choices=["relaxed", "cautious"])
     ap.add_argument("--taxon", default="custom", choices=["custom", "bacteria", "fungi", "eukaryotes"])
     ap.add_argument("--cpu-sample", type=int, default=500000, help="queries of the workload timed on the CPU oracle")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank holds the full per-GPU workload; strong: the workload is split over the ranks "
+                         "(BASELINE config #4: 10M queries sharded across 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
     args = ap.parse_args()
@@ -69,6 +72,8 @@ def main():
         cfg["n_queries"] = args.queries
     if args.taxa:
         cfg["n_taxa"] = args.taxa
+    if args.scaling == "strong" and world > 1:
+        cfg["n_queries"] = (cfg["n_queries"] + world - 1) // world      # per-GPU query slice of one fixed table
     seed = synth.SEEDS[args.config]
     custom = CUSTOM_16S if args.taxon == "custom" else None
 
@@ -177,7 +182,7 @@ def main():
         line = {
             "metric": "Mqueries/sec consensus (synthetic outfmt-6 hit table)",
             "value": value, "unit": "Mqueries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "i32+f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {Q} queries x "
                                    f"{cfg['hits_per_query'] if cfg['zipf'] is None else 'Zipf' + str(cfg['zipf'])} hits per GPU, "

@@ -52,8 +52,8 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     if (hits->on_device) {
         HitsDev hd{hits->bitscore, hits->tax_row, hits->pident, hits->align_len, hits->acc_rank, hits->seg_off,
                    hits->n_hits, hits->n_queries};
-        uint32_t* cur = tax->ws_count + tax->ws_parity;
-        uint32_t* nxt = tax->ws_count + (tax->ws_parity ^ 1u);
+        uint32_t* cur = tax->ws_count + 4 * tax->ws_parity;          // {queue length, -, take counter, -}
+        uint32_t* nxt = tax->ws_count + 4 * (tax->ws_parity ^ 1u);
         tax->ws_parity ^= 1u;
         return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus, tax->ws_worklist, cur, nxt);
     }
@@ -83,8 +83,8 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         HitsDev hd{(const int32_t*)d_bs, (const uint32_t*)d_tax, (const double*)d_pid, (const int32_t*)d_aln,
                    (const uint32_t*)d_acc, (const uint64_t*)d_seg, hits->n_hits, hits->n_queries};
         {
-            uint32_t* cur = tax->ws_count + tax->ws_parity;
-            uint32_t* nxt = tax->ws_count + (tax->ws_parity ^ 1u);
+            uint32_t* cur = tax->ws_count + 4 * tax->ws_parity;
+            uint32_t* nxt = tax->ws_count + 4 * (tax->ws_parity ^ 1u);
             tax->ws_parity ^= 1u;
             rc = launch_consensus(td, hd, params->strategy, (blu_result*)d_out, s, tax->device, tax->num_cus, tax->ws_worklist, cur, nxt);
         }

@@ -5,16 +5,18 @@
 // build_blast_consensus_identity.rs:9-105 (restated in SURVEY §3.3).
 //
 // Kernel A  blu_consensus_stream_kernel — the streaming path (segments <= 64 hits).
-//   A wave task is 64 consecutive queries.
-//   phase 1 (lane = hit): per query, coalesced loads of the five SoA columns,
-//     M = max bit_score by a DPP row reduction, top group = ballot(bs == M); the
-//     top rows (tax_row, align_len, accession rank, position, pident) are
-//     compacted in file order into a per-wave LDS list.  BATCH queries are in
-//     flight per wave so the HBM stream never waits on the reductions.
-//   phase 2 (lane = query): each lane walks its own top group out of LDS:
-//     lineage-row gathers (64-byte rows, L2/MALL), reference-row selection by
-//     the stable-sort rule, first disagreeing level, cutoff tests against the
-//     per-shape table, one 32-byte record.
+//   A wave task is 64 consecutive queries; the waves of a block take consecutive tasks.
+//   phase 1 (lane = 4 consecutive hit rows, 16 lanes per query, 4 queries per step):
+//     16-byte buffer loads of the five SoA columns, M = max bit_score by a 16-lane
+//     DPP row reduction, top rows ranked by a DPP row scan and compacted in file
+//     order into a per-wave LDS list (row id, align_len, accession rank, position,
+//     pident).  The row id carries the lineage length: no taxonomy lookup here.
+//   phase 2a (lane = query, LDS only): parse errors, reference row by the stable-sort
+//     rule, shortest lineage, group-max pident, span in sorted lineage order; the
+//     first disagreeing level is a range minimum over the adjacent-row LCP array.
+//   phase 2c (lane = query): one 128-byte line of the reference row gives the node
+//     ids, per-level cutoff ids (values in LDS) and rank codes; cutoff tests; record.
+//   Records are staged in LDS and leave as one write-through burst per block.
 //   Queries with more than 64 hits, or whose top group does not fit the LDS
 //   list, are appended to a worklist.
 // Kernel B  blu_consensus_long_kernel — worklist queries, one wave per query,
@@ -22,6 +24,8 @@
 //
 // Integer/compare work only: no MFMA.  The roofline is the HBM stream of the
 // five columns (24 B/hit) + 8 B offsets + 32 B record per query.
+// BLU_EXP_* macros are timing-only experiment hooks (scripts/build_variants.sh);
+// the product build defines none of them.
 #include <hip/hip_runtime.h>
 
 #include <climits>
@@ -36,9 +40,6 @@ namespace blu {
 #define BLOCK_A 512   // 8 waves = 8 consecutive tasks per block step: 16 KiB record bursts (256: +1.4 % time, 1024: +9 %)
 #endif
 #define WAVES_A (BLOCK_A / WAVE)
-#ifndef BATCH
-#define BATCH 4            // queries in flight per wave in phase 1
-#endif
 #ifndef LIST_CAP
 #define LIST_CAP 224       // top-group entries per wave task (64 queries; mean ~183, sigma ~18 at geometric(0.35) groups)
 #endif
@@ -822,7 +823,7 @@ static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hip
     g_grid = grid;
     g_block = BLOCK_A;
     hipLaunchKernelGGL(blu_consensus_stream_kernel<STRAT>, dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count, next_count);
-    const uint32_t grid_b = (uint32_t)(num_cus > 0 ? num_cus : 256) * 4u;
+    const uint32_t grid_b = (uint32_t)(num_cus > 0 ? num_cus : 256) * 8u;   // 32 waves per CU: the kernel is latency-bound per query
     hipLaunchKernelGGL(blu_consensus_long_kernel<STRAT>, dim3(grid_b), dim3(256), 0, s, hits, tax, out, worklist, work_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("kernel launch failed: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
