@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank holds the full per-GPU workload; strong: the workload is split over the ranks "
                          "(BASELINE config #4: 10M queries sharded across 8 GPUs)")
+    ap.add_argument("--pident", default="milli", choices=["milli", "f64"],
+                    help="hit-table layout: perc_identity as milli-percent u32 (lossless for BLAST's 3-decimal values, "
+                         "20 B/hit) or as f64 (24 B/hit, the canonical layout of BASELINE.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
     args = ap.parse_args()
@@ -86,12 +89,12 @@ def main():
     t_up = time.time() - t0
     t0 = time.time()
     hits = synth.make_hits(tax, cfg["n_queries"], seed, cfg["hits_per_query"], zipf=cfg["zipf"], device=dev,
-                           q_offset=rank * cfg["n_queries"])
+                           q_offset=rank * cfg["n_queries"], columns=args.pident)
     torch.cuda.synchronize()
     t_hits = time.time() - t0
     Q, Hn = hits.n_queries, hits.n_hits
     out = torch.zeros(32 * Q, dtype=torch.uint8, device=dev)
-    hd = hits.as_dict()
+    hd = hits.as_dict(args.pident)
     # the join of the hit table with the taxonomy (mod.rs:72-76): desc row -> engine row id, done once at ingest.
     # The oracle legs read the desc rows of the sampled prefix, kept aside.
     S_keep = min(Q, max(args.cpu_sample, 1))
@@ -118,6 +121,8 @@ def main():
         nrow = int(seg[-1])
         samp = {k: v[:nrow].cpu().numpy() for k, v in hd.items() if k not in ("seg_off", "tax_row")}
         samp["tax_row"] = desc_rows_sample[:nrow]
+        if args.pident == "milli":   # the oracle reads the f64 the reference's parser would produce: k / 1000, correctly rounded
+            samp["pident"] = samp.pop("pident_milli").astype(np.float64) / 1000.0
         got = engine.records_from_tensor(out[: 32 * S])
         exp = orc.columnar_run(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, seg, samp["bitscore"],
                                samp["tax_row"], samp["pident"], samp["align_len"], samp["acc_rank"],
@@ -169,13 +174,14 @@ def main():
         total_q = Q * world
         value = total_q * args.steps / elapsed / 1e6
         k_ms = float(np.mean(kernel_ms))
-        alg_bytes = hits.algorithmic_bytes()
+        alg_bytes = hits.algorithmic_bytes(args.pident)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.config, {}).get("traffic_bytes_per_launch")
+                tkey = args.config if args.pident == "f64" else args.config + "-milli"
+                traffic = json.load(open(tfile)).get(tkey, {}).get("traffic_bytes_per_launch")
             except Exception:
                 traffic = None
         name, grid, block = engine.last_launch()
@@ -186,9 +192,10 @@ def main():
             "dtype": "i32+f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {Q} queries x "
                                    f"{cfg['hits_per_query'] if cfg['zipf'] is None else 'Zipf' + str(cfg['zipf'])} hits per GPU, "
-                                   f"{tax.n}-taxid synthetic taxonomy, strategy {args.strategy}, taxon {args.taxon}",
+                                   f"{tax.n}-taxid synthetic taxonomy, strategy {args.strategy}, taxon {args.taxon}, "
+                                   f"perc_identity column {'milli-percent u32 (lossless, 20 B/hit)' if args.pident == 'milli' else 'f64 (24 B/hit)'}",
                        "queries_per_gpu": Q, "hit_rows_per_gpu": Hn, "taxids": tax.n, "strategy": args.strategy,
-                       "taxon": args.taxon, "seed": hex(seed), "generator_version": synth.GENERATOR_VERSION,
+                       "taxon": args.taxon, "pident_layout": args.pident, "bytes_per_hit": 20 if args.pident == "milli" else 24, "seed": hex(seed), "generator_version": synth.GENERATOR_VERSION,
                        "parallelism": f"query-sharded x{world}, taxonomy replicated, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

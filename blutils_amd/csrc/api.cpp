@@ -31,8 +31,11 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     if (hits->n_hits >= 0xFFFFFFFFull) { set_error("n_hits must be < 2^32 - 1 per call"); return BLU_ERR_INVALID_ARG; }
     if (hits->n_queries == 0) return BLU_OK;
     if (!out || !hits->seg_off) { set_error("null output or seg_off"); return BLU_ERR_INVALID_ARG; }
-    if (hits->n_hits && (!hits->bitscore || !hits->tax_row || !hits->pident || !hits->align_len || !hits->acc_rank)) {
+    if (hits->n_hits && (!hits->bitscore || !hits->tax_row || !hits->align_len || !hits->acc_rank)) {
         set_error("null hit column"); return BLU_ERR_INVALID_ARG;
+    }
+    if (hits->n_hits && ((hits->pident != nullptr) == (hits->pident_milli != nullptr))) {
+        set_error("exactly one of pident / pident_milli must be given"); return BLU_ERR_INVALID_ARG;
     }
     if (hipSetDevice(tax->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", tax->device); return BLU_ERR_NO_DEVICE; }
 
@@ -50,7 +53,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         tax->ws_capacity = hits->n_queries;
     }
     if (hits->on_device) {
-        HitsDev hd{hits->bitscore, hits->tax_row, hits->pident, hits->align_len, hits->acc_rank, hits->seg_off,
+        HitsDev hd{hits->bitscore, hits->tax_row, hits->pident, hits->pident_milli, hits->align_len, hits->acc_rank, hits->seg_off,
                    hits->n_hits, hits->n_queries};
         uint32_t* cur = tax->ws_count + 4 * tax->ws_parity;          // {queue length, -, take counter, -}
         uint32_t* nxt = tax->ws_count + 4 * (tax->ws_parity ^ 1u);
@@ -67,7 +70,8 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         const size_t pad = 64;  // keeps zero-length columns allocatable
         HIP_TRY(hipMalloc(&d_bs, nh * 4 + pad));
         HIP_TRY(hipMalloc(&d_tax, nh * 4 + pad));
-        HIP_TRY(hipMalloc(&d_pid, nh * 8 + pad));
+        const bool milli = hits->pident_milli != nullptr;
+        HIP_TRY(hipMalloc(&d_pid, nh * (milli ? 4 : 8) + pad));
         HIP_TRY(hipMalloc(&d_aln, nh * 4 + pad));
         HIP_TRY(hipMalloc(&d_acc, nh * 4 + pad));
         HIP_TRY(hipMalloc(&d_seg, (nq + 1) * 8));
@@ -75,12 +79,14 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         if (nh) {
             HIP_TRY(hipMemcpyAsync(d_bs, hits->bitscore, nh * 4, hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(d_tax, hits->tax_row, nh * 4, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpyAsync(d_pid, hits->pident, nh * 8, hipMemcpyHostToDevice, s));
+            if (milli) HIP_TRY(hipMemcpyAsync(d_pid, hits->pident_milli, nh * 4, hipMemcpyHostToDevice, s));
+            else HIP_TRY(hipMemcpyAsync(d_pid, hits->pident, nh * 8, hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(d_aln, hits->align_len, nh * 4, hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(d_acc, hits->acc_rank, nh * 4, hipMemcpyHostToDevice, s));
         }
         HIP_TRY(hipMemcpyAsync(d_seg, hits->seg_off, (nq + 1) * 8, hipMemcpyHostToDevice, s));
-        HitsDev hd{(const int32_t*)d_bs, (const uint32_t*)d_tax, (const double*)d_pid, (const int32_t*)d_aln,
+        HitsDev hd{(const int32_t*)d_bs, (const uint32_t*)d_tax, milli ? nullptr : (const double*)d_pid,
+                   milli ? (const uint32_t*)d_pid : nullptr, (const int32_t*)d_aln,
                    (const uint32_t*)d_acc, (const uint64_t*)d_seg, hits->n_hits, hits->n_queries};
         {
             uint32_t* cur = tax->ws_count + 4 * tax->ws_parity;

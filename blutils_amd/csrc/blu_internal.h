@@ -57,7 +57,8 @@ struct TaxDev {
 struct HitsDev {
     const int32_t* bitscore;
     const uint32_t* tax_row;
-    const double* pident;
+    const double* pident;          // f64 layout, or nullptr
+    const uint32_t* pident_milli;  // milli-percent layout, or nullptr
     const int32_t* align_len;
     const uint32_t* acc_rank;
     const uint64_t* seg_off;

@@ -141,6 +141,11 @@ __device__ __forceinline__ void store_status(blu_result* out, uint64_t q, uint32
     store_result(out, q, status, 0, BLU_NONE_U8, BLU_NONE_U8, BLU_NONE_U16, BLU_NONE_U16, 0xFFFFFFFFu, ref_row, 0ull, 0.0);
 }
 
+// perc_identity from its milli-percent encoding: the correctly rounded k / 1000, i.e. the double the reference's text
+// parser yields for a value printed with at most three decimals (IEEE f64 division; this file is built without
+// fast-math)
+__device__ __forceinline__ double milli_to_f64(uint32_t k) { return (double)k / 1000.0; }
+
 // packed level word of a lineage row -> the ABI's 16-bit rank codes
 __device__ __forceinline__ uint32_t packed_rank(uint32_t p) { return (p >> BLU_PACK_CUT_BITS) & BLU_PACK_CODE_MASK; }
 __device__ __forceinline__ uint32_t packed_mar(uint32_t p) {
@@ -236,7 +241,7 @@ struct WaveLds {
 #ifndef BLU_WAVES_PER_SIMD
 #define BLU_WAVES_PER_SIMD 1
 #endif
-template <int STRAT>
+template <int STRAT, bool PID32>
 __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                        uint32_t* __restrict__ worklist,
                                                                        uint32_t* __restrict__ work_count,
@@ -294,7 +299,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         const auto rs_tax = __builtin_amdgcn_make_buffer_rsrc((void*)(h.tax_row + task_start), 0, rem4, 0x00020000);
         const auto rs_aln = __builtin_amdgcn_make_buffer_rsrc((void*)(h.align_len + task_start), 0, rem4, 0x00020000);
         const auto rs_acc = __builtin_amdgcn_make_buffer_rsrc((void*)(h.acc_rank + task_start), 0, rem4, 0x00020000);
-        const auto rs_pid = __builtin_amdgcn_make_buffer_rsrc((void*)(h.pident + task_start), 0, rem8, 0x00020000);
+        const auto rs_pid = PID32 ? __builtin_amdgcn_make_buffer_rsrc((void*)(h.pident_milli + task_start), 0, rem4, 0x00020000)
+                                  : __builtin_amdgcn_make_buffer_rsrc((void*)(h.pident + task_start), 0, rem8, 0x00020000);
         // per-query {first row, row count} of the task, relative to task_start; count 0 also for segments > 64 rows
         // (those go to the worklist in phase 2a) so that phase 1 simply finds no top row in them
         {
@@ -308,28 +314,22 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             const uint2 sg = L.seg[qi];
             const int left = (int)sg.y - (int)sub4;              // rows of the segment from this lane's first row on
             const uint32_t voff = (sg.x + sub4) * 4u;
-#ifndef BLU_EXP_UNCOND_LOADS
-            // lanes past the end of the segment issue nothing (a few % fewer L1 requests than reading on into the
-            // next query's rows); their registers stay undefined and are masked by `left` below
+            // lanes past the end of the segment issue nothing; their registers stay undefined and are masked by `left`
+            // below.  No VALU write touches a register with a load in flight, so nothing waits in front of the issue.
             u32x4 vbs, vtax, vp01, vp23, valn, vacc;
             if (left > 0) {
                 vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
                 vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, voff, 0, STREAM_AUX);
-                vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u, 0, STREAM_AUX);
-                vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u + 16u, 0, STREAM_AUX);
+                if (PID32) {
+                    vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff, 0, STREAM_AUX);   // four milli-percent values
+                    vp23 = vp01;
+                } else {
+                    vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u, 0, STREAM_AUX);
+                    vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u + 16u, 0, STREAM_AUX);
+                }
                 valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, voff, 0, STREAM_AUX);
                 vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, voff, 0, STREAM_AUX);
             }
-#else
-            // unconditional 16-byte loads (lanes past the segment read the next query's rows, or 0 past the table):
-            // no VALU write touches a register with a load in flight, so nothing waits in front of the issue
-            const u32x4 vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
-            const u32x4 vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, voff, 0, STREAM_AUX);
-            const u32x4 vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u, 0, STREAM_AUX);
-            const u32x4 vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u + 16u, 0, STREAM_AUX);
-            const u32x4 valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, voff, 0, STREAM_AUX);
-            const u32x4 vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, voff, 0, STREAM_AUX);
-#endif
             // every loaded register is read here on every path (see the note on vmcnt at the loop head)
             asm volatile("" ::"v"(vbs), "v"(vtax), "v"(vp01), "v"(vp23), "v"(valn), "v"(vacc));
 #ifdef BLU_EXP_NOREDUCE
@@ -357,6 +357,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             const bool tt[4] = {t0, t1, t2, t3};
             const uint32_t xt[4] = {vtax.x, vtax.y, vtax.z, vtax.w}, xa[4] = {valn.x, valn.y, valn.z, valn.w};
             const uint32_t xc[4] = {vacc.x, vacc.y, vacc.z, vacc.w};
+            const uint32_t xm[4] = {vp01.x, vp01.y, vp01.z, vp01.w};   // PID32 layout
             const double xp[4] = {__hiloint2double((int)vp01.y, (int)vp01.x), __hiloint2double((int)vp01.w, (int)vp01.z),
                                   __hiloint2double((int)vp23.y, (int)vp23.x), __hiloint2double((int)vp23.w, (int)vp23.z)};
 #pragma unroll
@@ -367,7 +368,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 if (fits && tt[r]) {
 #endif
                     Entry e;
-                    e.id = xt[r]; e.aln = xa[r]; e.acc = xc[r]; e.pq = (sub4 + r) | (qi << 8); e.pid = xp[r];
+                    e.id = xt[r]; e.aln = xa[r]; e.acc = xc[r]; e.pq = (sub4 + r) | (qi << 8);
+                    e.pid = PID32 ? milli_to_f64(xm[r]) : xp[r];
                     L.list[idx] = e;   // the row id carries the lineage length: phase 1 touches no taxonomy table
                     ++idx;
                 }
@@ -627,7 +629,7 @@ __device__ __forceinline__ int select_reference(bool valid, uint32_t len, uint32
     return first_lane(cand);
 }
 
-template <int STRAT>
+template <int STRAT, bool PID32>
 __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                  const uint32_t* __restrict__ worklist,
                                                                  const uint32_t* __restrict__ work_count) {
@@ -644,7 +646,8 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
         const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)(end - start));   // n_hits < 2^32
         const int32_t* c_bs = h.bitscore + start;
         const uint32_t* c_tax = h.tax_row + start;
-        const double* c_pid = h.pident + start;
+        const double* c_pid = PID32 ? nullptr : h.pident + start;
+        const uint32_t* c_pm = PID32 ? h.pident_milli + start : nullptr;
         const int32_t* c_aln = h.align_len + start;
         const uint32_t* c_acc = h.acc_rank + start;
         // pass 1: top score
@@ -689,7 +692,7 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             k += (uint32_t)__builtin_popcountll(mask);
             const uint32_t ii = top ? i : 0;
             const uint32_t tax = c_tax[ii];
-            const double pid = c_pid[ii];
+            const double pid = PID32 ? milli_to_f64(c_pm[ii]) : c_pid[ii];
             const int aln = c_aln[ii];
             const uint32_t acc = c_acc[ii];
             const uint32_t pos = tax & ROW_MASK;
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             for (uint32_t base = 0; base < n; base += WAVE) {
                 const uint32_t i = base + (uint32_t)lane;
                 const bool top = i < n && c_bs[i < n ? i : 0] == M;
-                const double pid = c_pid[top ? i : 0];
+                const double pid = PID32 ? milli_to_f64(c_pm[top ? i : 0]) : c_pid[top ? i : 0];
                 const uint64_t nm = __ballot(top && pid != pid);
                 if (nm) { nan_row = base + first_lane(nm); break; }
             }
@@ -809,11 +812,11 @@ void consensus_last_geometry(uint32_t* grid, uint32_t* block) {
     if (block) *block = g_block;
 }
 
-template <int STRAT>
+template <int STRAT, bool PID32>
 static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hipStream_t s, int num_cus,
                     uint32_t* worklist, uint32_t* work_count, uint32_t* next_count) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blu_consensus_stream_kernel<STRAT>, BLOCK_A, 0) != hipSuccess || per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blu_consensus_stream_kernel<STRAT, PID32>, BLOCK_A, 0) != hipSuccess || per_cu <= 0)
         per_cu = 2;
     const uint64_t n_tasks = (hits.n_queries + WAVE - 1) / WAVE;
     const uint64_t want = (n_tasks + WAVES_A - 1) / WAVES_A;
@@ -822,9 +825,9 @@ static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hip
     if (grid == 0) grid = 1;
     g_grid = grid;
     g_block = BLOCK_A;
-    hipLaunchKernelGGL(blu_consensus_stream_kernel<STRAT>, dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count, next_count);
+    hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, PID32>), dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count, next_count);
     const uint32_t grid_b = (uint32_t)(num_cus > 0 ? num_cus : 256) * 8u;   // 32 waves per CU: the kernel is latency-bound per query
-    hipLaunchKernelGGL(blu_consensus_long_kernel<STRAT>, dim3(grid_b), dim3(256), 0, s, hits, tax, out, worklist, work_count);
+    hipLaunchKernelGGL((blu_consensus_long_kernel<STRAT, PID32>), dim3(grid_b), dim3(256), 0, s, hits, tax, out, worklist, work_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("kernel launch failed: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
     return BLU_OK;
@@ -834,8 +837,13 @@ int launch_consensus(const TaxDev& tax, const HitsDev& hits, int strategy, blu_r
                      int num_cus, uint32_t* worklist, uint32_t* work_count, uint32_t* next_count) {
     (void)device;
     if (hits.n_queries == 0) return BLU_OK;
-    if (strategy == BLU_RELAXED) return launch_t<BLU_RELAXED>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count, next_count);
-    return launch_t<BLU_CAUTIOUS>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count, next_count);
+    const bool milli = hits.pident_milli != nullptr;
+    if (strategy == BLU_RELAXED) {
+        if (milli) return launch_t<BLU_RELAXED, true>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count, next_count);
+        return launch_t<BLU_RELAXED, false>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count, next_count);
+    }
+    if (milli) return launch_t<BLU_CAUTIOUS, true>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count, next_count);
+    return launch_t<BLU_CAUTIOUS, false>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count, next_count);
 }
 
 }  // namespace blu

@@ -155,21 +155,26 @@ class Taxonomy:
 
 
 def run_consensus_host(tax: Taxonomy, seg_off, bitscore, tax_row, pident, align_len, acc_rank,
-                       strategy: str = "relaxed") -> np.ndarray:
-    """Host buffers in, host records out; the library stages them over PCIe.  tax_row: ENGINE row ids."""
+                       strategy: str = "relaxed", pident_milli=None) -> np.ndarray:
+    """Host buffers in, host records out; the library stages them over PCIe.  tax_row: ENGINE row ids.
+    pident_milli (uint32, perc_identity * 1000) replaces the f64 `pident` column when given (pass pident=None)."""
     seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
     bs = np.ascontiguousarray(bitscore, dtype=np.int32)
     tx = np.ascontiguousarray(tax_row)
     tx = tx.view(np.uint32) if tx.dtype == np.int32 else np.ascontiguousarray(tx, dtype=np.uint32)
-    pid = np.ascontiguousarray(pident, dtype=np.float64)
+    pid = np.ascontiguousarray(pident, dtype=np.float64) if pident_milli is None else None
+    pm = None
+    if pident_milli is not None:
+        pm = np.ascontiguousarray(pident_milli)
+        pm = pm.view(np.uint32) if pm.dtype == np.int32 else np.ascontiguousarray(pm, dtype=np.uint32)
     aln = np.ascontiguousarray(align_len, dtype=np.int32)
     ac = np.ascontiguousarray(acc_rank)
     ac = ac.view(np.uint32) if ac.dtype == np.int32 else np.ascontiguousarray(ac, dtype=np.uint32)
     nq = len(seg) - 1
     nh = int(seg[-1])
-    assert len(bs) == nh and len(tx) == nh and len(pid) == nh and len(aln) == nh and len(ac) == nh
-    hits = N.Hits(bs.ctypes.data, tx.ctypes.data, pid.ctypes.data, aln.ctypes.data, ac.ctypes.data, seg.ctypes.data,
-                  nh, nq, 0, 0)
+    assert len(bs) == nh and len(tx) == nh and len(pid if pm is None else pm) == nh and len(aln) == nh and len(ac) == nh
+    hits = N.Hits(bs.ctypes.data, tx.ctypes.data, pid.ctypes.data if pm is None else None, aln.ctypes.data, ac.ctypes.data,
+                  seg.ctypes.data, nh, nq, 0, 0, pm.ctypes.data if pm is not None else None)
     params = N.RunParams(N.STRATEGY[strategy], 0, None)
     out = np.zeros(nq, dtype=RESULT_DTYPE)
     rc = N.lib().blu_consensus_run(tax.handle, C.byref(hits), C.byref(params), out.ctypes.data)
@@ -179,21 +184,25 @@ def run_consensus_host(tax: Taxonomy, seg_off, bitscore, tax_row, pident, align_
 
 
 def run_consensus_device(tax: Taxonomy, hits: dict, out, strategy: str = "relaxed", stream: Optional[int] = None):
-    """torch CUDA tensors in (`hits` keys: seg_off bitscore tax_row pident align_len acc_rank), records into the
-    uint8 CUDA tensor `out` of 32 * n_queries bytes.  Asynchronous on `stream` (default: torch's current stream)."""
+    """torch CUDA tensors in (`hits` keys: seg_off bitscore tax_row align_len acc_rank and either pident (float64) or
+    pident_milli (int32 bit pattern of uint32)), records into the uint8 CUDA tensor `out` of 32 * n_queries bytes.
+    Asynchronous on `stream` (default: torch's current stream)."""
     import torch
 
     nq = hits["seg_off"].numel() - 1
     nh = hits["bitscore"].numel()
+    milli = hits.get("pident_milli") is not None
     for k, dt in (("seg_off", torch.int64), ("bitscore", torch.int32), ("tax_row", torch.int32),
-                  ("pident", torch.float64), ("align_len", torch.int32), ("acc_rank", torch.int32)):
+                  ("pident_milli", torch.int32) if milli else ("pident", torch.float64), ("align_len", torch.int32),
+                  ("acc_rank", torch.int32)):
         t = hits[k]
         assert t.is_cuda and t.is_contiguous() and t.dtype == dt, (k, t.dtype, t.device)
     assert out.is_cuda and out.is_contiguous() and out.numel() * out.element_size() >= 32 * nq
     if stream is None:
         stream = torch.cuda.current_stream().cuda_stream
-    h = N.Hits(hits["bitscore"].data_ptr(), hits["tax_row"].data_ptr(), hits["pident"].data_ptr(),
-               hits["align_len"].data_ptr(), hits["acc_rank"].data_ptr(), hits["seg_off"].data_ptr(), nh, nq, 1, 0)
+    h = N.Hits(hits["bitscore"].data_ptr(), hits["tax_row"].data_ptr(), None if milli else hits["pident"].data_ptr(),
+               hits["align_len"].data_ptr(), hits["acc_rank"].data_ptr(), hits["seg_off"].data_ptr(), nh, nq, 1, 0,
+               hits["pident_milli"].data_ptr() if milli else None)
     params = N.RunParams(N.STRATEGY[strategy], 0, stream)
     rc = N.lib().blu_consensus_run(tax.handle, C.byref(h), C.byref(params), out.data_ptr())
     if rc != N.BLU_OK:

@@ -238,27 +238,34 @@ class SynthHits:
     seg_off: "object"     # int64 [Q+1] (bit pattern of uint64)
     bitscore: "object"    # int32
     tax_row: "object"     # int32 (bit pattern of uint32, -1 = BLU_UNMATCHED_TAXID)
-    pident: "object"      # float64
+    pident: "object"      # float64 (None when only the milli-percent column was generated)
     align_len: "object"   # int32
     acc_rank: "object"    # int32 (bit pattern of uint32)
     n_queries: int = 0
     n_hits: int = 0
+    pident_milli: "object" = None   # int32: perc_identity * 1000 (the generator draws 3-decimal values)
 
-    def as_dict(self):
-        return {"seg_off": self.seg_off, "bitscore": self.bitscore, "tax_row": self.tax_row, "pident": self.pident,
-                "align_len": self.align_len, "acc_rank": self.acc_rank}
+    def as_dict(self, layout: str = "f64"):
+        """layout "f64": the canonical 24 B/hit columns; "milli": pident as milli-percent uint32, 20 B/hit."""
+        d = {"seg_off": self.seg_off, "bitscore": self.bitscore, "tax_row": self.tax_row,
+             "align_len": self.align_len, "acc_rank": self.acc_rank}
+        if layout == "milli":
+            d["pident_milli"] = self.pident_milli
+        else:
+            d["pident"] = self.pident
+        return d
 
     def numpy(self):
         return {k: v.detach().cpu().numpy() for k, v in self.as_dict().items()}
 
-    def algorithmic_bytes(self) -> int:
-        """SURVEY §8d / BASELINE.md §3: 24·H + 8·(Q+1) + 32·Q."""
-        return 24 * self.n_hits + 8 * (self.n_queries + 1) + 32 * self.n_queries
+    def algorithmic_bytes(self, layout: str = "f64") -> int:
+        """SURVEY §8d / BASELINE.md §3: (24 | 20)·H + 8·(Q+1) + 32·Q — the bytes of the layout actually read."""
+        return (20 if layout == "milli" else 24) * self.n_hits + 8 * (self.n_queries + 1) + 32 * self.n_queries
 
 
 def make_hits(tax: SynthTaxonomy, n_queries: int, seed: int, hits_per_query: Optional[int] = 50,
               zipf: Optional[tuple] = None, device: str = "cpu", p_unmatched: float = 0.0005,
-              chunk_queries: int = 1 << 20, q_offset: int = 0, tables=None) -> SynthHits:
+              chunk_queries: int = 1 << 20, q_offset: int = 0, tables=None, columns: str = "both") -> SynthHits:
     """Hit table in SoA form.  hits_per_query fixed, or zipf=(s, lo, hi) for the skewed config.
 
     q_offset shifts the query counter (rank r of a multi-GPU run generates its own slice of one
@@ -281,9 +288,11 @@ def make_hits(tax: SynthTaxonomy, n_queries: int, seed: int, hits_per_query: Opt
     torch.cumsum(nq, 0, out=seg[1:])
     H = int(seg[-1].item())
     assert H < (1 << 32) - 1, "n_hits must stay below 2^32 - 1 per call"
+    # columns: "both" (f64 and milli-percent pident), "f64" or "milli" (saves 4 / 8 bytes per hit of device memory)
     out = SynthHits(seg, torch.empty(H, dtype=torch.int32, device=dev), torch.empty(H, dtype=torch.int32, device=dev),
-                    torch.empty(H, dtype=torch.float64, device=dev), torch.empty(H, dtype=torch.int32, device=dev),
-                    torch.empty(H, dtype=torch.int32, device=dev), Q, H)
+                    torch.empty(H, dtype=torch.float64, device=dev) if columns != "milli" else None,
+                    torch.empty(H, dtype=torch.int32, device=dev), torch.empty(H, dtype=torch.int32, device=dev), Q, H,
+                    torch.empty(H, dtype=torch.int32, device=dev) if columns != "f64" else None)
     if tables is None:
         tables = {}
     if "lo" not in tables or tables["lo"].device != dev:
@@ -342,7 +351,10 @@ def make_hits(tax: SynthTaxonomy, n_queries: int, seed: int, hits_per_query: Opt
         taxr = torch.where(miss, torch.full_like(subj, 0xFFFFFFFF), subj)
         out.bitscore[r0:r1] = bs.to(torch.int32)
         out.tax_row[r0:r1] = torch.where(taxr >= (1 << 31), taxr - (1 << 32), taxr).to(torch.int32)
-        out.pident[r0:r1] = pid_t[pid_m]
+        if out.pident is not None:
+            out.pident[r0:r1] = pid_t[pid_m]
+        if out.pident_milli is not None:
+            out.pident_milli[r0:r1] = pid_m.to(torch.int32)
         out.align_len[r0:r1] = aln.to(torch.int32)
         out.acc_rank[r0:r1] = torch.where(acc >= (1 << 31), acc - (1 << 32), acc).to(torch.int32)
     return out

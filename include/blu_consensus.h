@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BLU_ABI_VERSION 1u
+#define BLU_ABI_VERSION 2u
 #define BLU_UNMATCHED_TAXID 0xFFFFFFFFu /* hit whose subject_taxid is not in the taxonomy (left join miss, mod.rs:72-76) */
 #define BLU_MAX_DEPTH 64u               /* level_mask is 64 bits wide */
 #define BLU_ROW_BITS 25u                /* engine row id = sorted position | lineage length << 25: at most 2^25 taxids */
@@ -91,7 +91,7 @@ typedef struct blu_hits {
                                   the left join of mod.rs:72-76) or BLU_UNMATCHED_TAXID.  Engine row ids are opaque:
                                   the row's rank in lexicographic lineage order (low BLU_ROW_BITS bits) and its lineage
                                   length (bits above); they are NOT the desc row indices. */
-    const double* pident;      /* [n_hits] perc_identity */
+    const double* pident;      /* [n_hits] perc_identity as f64, or NULL when pident_milli is given */
     const int32_t* align_len;  /* [n_hits] */
     const uint32_t* acc_rank;  /* [n_hits] order-preserving rank of subject_accession (bytewise String::cmp) */
     const uint64_t* seg_off;   /* [n_queries + 1] row offsets, seg_off[0] = 0, seg_off[n_queries] = n_hits */
@@ -100,6 +100,11 @@ typedef struct blu_hits {
     int32_t on_device;         /* 1: every pointer (and `out`) is a device pointer on the handle's GPU;
                                   0: host pointers, the library stages them over PCIe */
     int32_t reserved;
+    const uint32_t* pident_milli; /* [n_hits] or NULL.  Narrow lossless encoding of perc_identity for tables whose
+                                  text has at most 3 decimals (BLAST outfmt 6 prints %.3f): k = perc_identity * 1000
+                                  as an exact integer.  The engine rebuilds the f64 the reference's parser produces,
+                                  the correctly rounded k / 1000, for the few rows that need it.  20 B/hit instead of
+                                  24.  Exactly one of pident / pident_milli is non-NULL. */
 } blu_hits;
 
 typedef struct blu_run_params {

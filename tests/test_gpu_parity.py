@@ -149,6 +149,37 @@ def test_adversarial_ties_and_prefix_lineages(seed):
         H.assert_matches_faithful(r.render(got[q]), faithful[q], q)
 
 
+def test_milli_percent_layout_gives_identical_records():
+    """perc_identity as milli-percent u32 (20 B/hit) is a lossless re-encoding of 3-decimal values: every record is
+    bit-identical to the f64 layout's, on the short path, the worklist path and the device-pointer path."""
+    import torch
+    tax = synth.make_taxonomy(30000, synth.SEEDS["C5"], deep=True)
+    dh = synth.make_hits(tax, 30000, synth.SEEDS["C5"], None, zipf=(1.1, 1, 3000), device="cuda")
+    t = _engine_tax(tax, "bacteria")
+    rows = t.engine_rows(dh.tax_row).contiguous()
+    outs = []
+    for layout in ("f64", "milli"):
+        hd = dh.as_dict(layout)
+        hd["tax_row"] = rows
+        out = torch.zeros(32 * dh.n_queries, dtype=torch.uint8, device="cuda")
+        engine.run_consensus_device(t, hd, out, strategy="relaxed")
+        torch.cuda.synchronize()
+        outs.append(engine.records_from_tensor(out))
+    assert outs[0].tobytes() == outs[1].tobytes()
+    h = dh.numpy()
+    assert np.array_equal(h["pident"], dh.pident_milli.cpu().numpy() / 1000.0)
+    _assert_records_equal(outs[1], H.columnar(tax, h, "bacteria", "relaxed", threads=8))
+    # host-pointer path, cautious, C1-like table
+    tax1 = synth.make_taxonomy(2000, synth.SEEDS["C1"])
+    d1 = synth.make_hits(tax1, 1000, synth.SEEDS["C1"], 10)
+    h1 = d1.numpy()
+    t1 = _engine_tax(tax1, "custom", H.CUSTOM_16S)
+    a = engine.run_consensus_host(t1, h1["seg_off"], h1["bitscore"], t1.engine_rows(h1["tax_row"]), h1["pident"], h1["align_len"], h1["acc_rank"], "cautious")
+    b = engine.run_consensus_host(t1, h1["seg_off"], h1["bitscore"], t1.engine_rows(h1["tax_row"]), None, h1["align_len"], h1["acc_rank"], "cautious",
+                                  pident_milli=d1.pident_milli.numpy())
+    assert a.tobytes() == b.tobytes()
+
+
 def _intern_lineages(lineages):
     """lineage strings -> CSR over interned canonical (rank, identifier) pairs."""
     ranks, rank_id, nodes = [], {}, {}
