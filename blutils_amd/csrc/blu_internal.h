@@ -27,15 +27,17 @@ struct RankInfo {
 // Lineage rows sit in LEXICOGRAPHIC order of their node sequences (row index = "pos"; engine row ids are
 // pos | lineage length << BLU_ROW_BITS, so the streaming phase needs no taxonomy lookup).  One row:
 //   word 0      len | shape << 8        (len 0 = lineage that fails parse_taxonomy)
-//   word 1      spare
-//   word 2+2j   node id of level j      interned (Display(rank), identifier)
-//   word 3+2j   cutoff id (12 bits) | canonical rank code (10 bits) << 12 | max-allowed-rank code (10 bits) << 22
-// i.e. everything the finalisation reads about the reference row — identifier, per-level cutoffs, rank codes —
-// in ONE 128-byte line for lineages of up to 15 levels (stride = 32 words; deeper taxonomies use longer rows
-// and only the first line is touched for shallow reference rows).  Cutoffs are stored by id into `cutvals`,
-// the table of the few hundred DISTINCT f64 cutoff values of this (taxonomy, backbone) pair, held in LDS.
+//   word 1+j    node id of level j      interned (Display(rank), identifier)
+// i.e. 64 bytes (half a cache line: one 64-byte memory request) for lineages of up to 15 levels; stride = 16 words
+// per 16 levels.  What the finalisation needs per LEVEL — cutoff, rank code, max-allowed-rank code — depends on the
+// row's shape only: codes[shape][cstride], one word per level =
+//   cutoff id (12 bits) | canonical rank code (10 bits) << 12 | max-allowed-rank code (10 bits) << 22
+// (a few hundred KB, re-read by every query, so it stays in L2).  Cutoffs are stored by id into `cutvals`, the
+// table of the few hundred DISTINCT f64 cutoff values of this (taxonomy, backbone) pair, held in LDS.
 struct TaxDev {
     const uint32_t* lin;     // [n_tax][stride]
+    const uint32_t* codes;   // [n_shapes][cstride]
+    uint32_t cstride;        // words per shape row, multiple of 16
     // lcp8[i] = number of leading levels shared by sorted rows i and i+1.  In that order the levels shared by a
     // whole group of rows = min(lcp8[lo .. hi-1]) for the group's smallest/largest pos: a range-minimum query
     // replaces the per-row level scan of find_multi_taxa_consensus.rs:137-180.
@@ -45,7 +47,7 @@ struct TaxDev {
     const double* cutvals;   // [n_cutvals] distinct cutoff values (NaN included, compared by bit pattern)
     uint32_t n_cutvals;
     uint64_t n_tax;
-    uint32_t stride;         // words per lineage row, multiple of 32 (128-byte lines)
+    uint32_t stride;         // words per lineage row, multiple of 16 (64 bytes)
     uint32_t max_depth;      // longest lineage: bounds the length bits of a (possibly corrupt) row id
 };
 
@@ -101,8 +103,9 @@ struct blu_taxonomy {
     uint32_t rmq_nb = 0;
     std::vector<uint32_t> pos_of;            // caller's tax_row -> sorted position
     double* d_cutvals = nullptr;
+    uint32_t* d_codes = nullptr;
     uint32_t n_cutvals = 0;
-    uint32_t dev_stride = 32;                // words per DEVICE row (interleaved layout); `stride` is the host layout's
+    uint32_t dev_stride = 16;                // words per DEVICE row (= stride: the device rows are the sorted host rows)
     uint64_t device_bytes = 0;
     // per-handle scratch of the run call (worklist of long / overflowing queries); grown on demand,
     // so one handle must not be used by two concurrent blu_consensus_run calls

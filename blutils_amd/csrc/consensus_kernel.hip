@@ -460,7 +460,11 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     // levels shared by the whole group (:137-180): every row agrees with the reference row on exactly
                     // the levels all rows share, and the scan never looks past the shortest lineage
                     d = minlen;
+#ifdef BLU_EXP_NORMQ
+                    if (k > 1 && lo < hi) d = umin(minlen, 1u + ((hi - lo) & 3u));
+#else
                     if (k > 1 && lo < hi) d = umin(minlen, shared_levels(t, lo, hi));
+#endif
                 }
             }
         }
@@ -477,22 +481,25 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             rec_kind = 1;
             if (!agree && d == 0) pack_status(ra, rb, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
             else {
-                // One 128-byte line of the reference row holds its node ids, per-level cutoff ids and rank codes
-                // (interleaved: word 2+2j = node, word 3+2j = cutoff id | rank code << 12 | max-allowed code << 22).
+                // The reference row (header + node ids) is 64 bytes for up to 15 levels: four 16-byte loads issued back
+                // to back = one 64-byte memory request.  Per-level cutoff ids and rank codes come from the row of its
+                // shape in the codes table (L2-resident: a few hundred KB re-read by every query).
 #ifdef BLU_EXP_NOREF
                 const uint32_t* ref = t.lin;
 #else
                 const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
 #endif
-#ifndef BLU_EXP_EARLY_HDR
-                r_hdr = ref[0];   // (requesting it back in phase 2a costs a second fetch: the line leaves L2 in between)
-#endif
-                // (the header word was requested in phase 2a, so the row's line is on its way; its length field equals
-                // the id's for a well-formed id and bounds the loop for a corrupt one)
+                const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
+                uint4 w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = ref4[k];
+                r_hdr = w[0].x;   // (requesting it back in phase 2a costs a second fetch: the line leaves L2 in between)
+                // its length field equals the id's for a well-formed id and bounds the loops for a corrupt one
                 const uint32_t len_ref = umin(r_len, r_hdr & 0xFF);
+                const uint32_t* codes = t.codes + (uint64_t)(r_hdr >> 8) * t.cstride;
+                const uint4* codes4 = reinterpret_cast<const uint4*>(codes);
                 const uint32_t b = single ? len_ref : (agree ? minlen - 1 : d - 1);
                 const double ident = (single | agree) ? r_pid : max_pid;
-                const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
                 // linnaean_ranks.rs:174-212 + build_blast_consensus_identity.rs:67-82
                 uint64_t F = 0, A = 0;
                 uint32_t mar_level = BLU_NONE_U8, nF = 0;
@@ -508,39 +515,44 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                         }
                     }
                 };
-                // chunk 0 = {header, spare, node 0, packed 0}; chunk k >= 1 = levels 2k-1 and 2k.  The first line of
-                // the row (levels 0..14) is read with eight loads issued back to back: the line is requested from
-                // memory once, instead of once per loop iteration after the stream has pushed it out of L2 again.
                 {
-                    uint4 w[8];
+                    uint4 c[4];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) w[k] = ref4[k];
-                    level(0, w[0].w);
+                    for (int k = 0; k < 4; ++k) c[k] = codes4[k];
 #pragma unroll
-                    for (int k = 1; k < 8; ++k) { level(2 * k - 1, w[k].y); level(2 * k, w[k].w); }
+                    for (int k = 0; k < 4; ++k) { level(4 * k, c[k].x); level(4 * k + 1, c[k].y); level(4 * k + 2, c[k].z); level(4 * k + 3, c[k].w); }
                 }
-                for (uint32_t k = 8; 2 * k - 1 < len_ref; ++k) {   // lineages deeper than 15 levels
-                    const uint4 x = ref4[k];
-                    level(2 * k - 1, x.y);
-                    level(2 * k, x.w);
+                for (uint32_t k = 4; 4 * k < len_ref; ++k) {   // lineages deeper than 16 levels
+                    const uint4 x = codes4[k];
+                    level(4 * k, x.x); level(4 * k + 1, x.y); level(4 * k + 2, x.z); level(4 * k + 3, x.w);
                 }
+                // node id of level j: words 1..15 are in registers, deeper levels are read from the row
+                const uint32_t nid[16] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w,
+                                          w[2].x, w[2].y, w[2].z, w[2].w, w[3].x, w[3].y, w[3].z, w[3].w};
+                auto node_of = [&](uint32_t j) {
+                    uint32_t v = 0;
+                    if (j >= 15) v = ref[1 + j];
+#pragma unroll
+                    for (uint32_t i = 1; i < 16; ++i) v = (j + 1 == i) ? nid[i] : v;
+                    return v;
+                };
                 if (agree) A = F;                                                  // single hit / single-flag branch (:74-75)
                 if (single) {
                     if (!A) pack_status(ra, rb, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, row0 + r_pos);   // find_single_query_consensus.rs:113-119
                     else {
                         const uint32_t last = (uint32_t)last_lane(A);
-                        pack_result(ra, rb, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, packed_rank(ref[3 + 2 * last]), BLU_NONE_U16,
-                                     ref[2 + 2 * last], row0 + r_pos, A, ident);
+                        pack_result(ra, rb, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, packed_rank(codes[last]), BLU_NONE_U16,
+                                     node_of(last), row0 + r_pos, A, ident);
                     }
                 } else {
                     const uint32_t last = A ? (uint32_t)last_lane(A) : b;          // .last().unwrap_or(taxonomy[bean_index])
                     uint32_t flags = agree ? BLU_FLAG_AGREE : 0u, mar_code = BLU_NONE_U16;
                     if (mar_level != BLU_NONE_U8) {
-                        mar_code = packed_mar(ref[3 + 2 * mar_level]);
-                        if (mar_code != packed_rank(ref[3 + 2 * b])) flags |= BLU_FLAG_MUTATED;   // bean.reached_rank != allowed_rank (:35-37)
+                        mar_code = packed_mar(codes[mar_level]);
+                        if (mar_code != packed_rank(codes[b])) flags |= BLU_FLAG_MUTATED;   // bean.reached_rank != allowed_rank (:35-37)
                     }
-                    pack_result(ra, rb, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, packed_rank(ref[3 + 2 * last]), mar_code,
-                                 ref[2 + 2 * last], row0 + r_pos, A, ident);
+                    pack_result(ra, rb, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, packed_rank(codes[last]), mar_code,
+                                 node_of(last), row0 + r_pos, A, ident);
                 }
             }
         }
@@ -756,8 +768,9 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
         const double pid_ref = rl_f64(b_pid, rlane);
         const bool in_l = (uint32_t)lane < len_ref;
         const uint32_t lvl = in_l ? (uint32_t)lane : 0u;
-        const uint32_t ref_node = t.lin[(uint64_t)row_ref * t.stride + 2 + 2 * lvl];
-        const uint32_t packed = t.lin[(uint64_t)row_ref * t.stride + 3 + 2 * lvl];
+        const uint32_t shape_ref = t.lin[(uint64_t)row_ref * t.stride] >> 8;
+        const uint32_t ref_node = t.lin[(uint64_t)row_ref * t.stride + 1 + lvl];
+        const uint32_t packed = t.codes[(uint64_t)shape_ref * t.cstride + lvl];
         const double cut = t.cutvals[packed & ((1u << BLU_PACK_CUT_BITS) - 1u)];
         const uint32_t codes = packed_rank(packed) | (packed_mar(packed) << 16);
         const uint32_t ref_row = (uint32_t)start + pos_ref;

@@ -722,7 +722,20 @@ int blu_build_consensus_identities(const char* blast_output_file, const char* co
     std::vector<blu_result> recs(ht.query_names.size());
     if (!recs.empty()) {
         blu_hits h{};
-        h.bitscore = ht.bitscore.data(); h.tax_row = eng_rows.data(); h.pident = ht.pident.data();
+        h.bitscore = ht.bitscore.data(); h.tax_row = eng_rows.data();
+        // 20 B/hit layout when every perc_identity is exactly k/1000 (BLAST prints <= 3 decimals): verified per value,
+        // so the engine's fl(k / 1000.0) is bit-identical to the parsed f64; otherwise the f64 column goes over.
+        std::vector<uint32_t> milli(ht.pident.size());
+        bool exact = true;
+        for (size_t i = 0; i < milli.size() && exact; ++i) {
+            const double p = ht.pident[i];
+            if (!(p >= 0.0 && p < 4.0e6)) { exact = false; break; }
+            const uint32_t k = (uint32_t)(p * 1000.0 + 0.5);
+            const double back = (double)k / 1000.0;
+            exact = memcmp(&back, &p, 8) == 0;
+            milli[i] = k;
+        }
+        if (exact) h.pident_milli = milli.data(); else h.pident = ht.pident.data();
         h.align_len = ht.align_len.data(); h.acc_rank = ht.acc_rank.data(); h.seg_off = ht.seg_off.data();
         h.n_hits = ht.bitscore.size(); h.n_queries = ht.query_names.size(); h.on_device = 0;
         blu_run_params rp{params->strategy, 0, nullptr};

@@ -295,23 +295,17 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         if (it == cut_ids.end()) { it = cut_ids.emplace(bits, (uint32_t)cutvals.size()).first; cutvals.push_back(v); }
         return it->second;
     };
-    const uint32_t dstride = ((2 + 2 * std::max<uint32_t>(tax->max_depth, 1) + 31) / 32) * 32;
-    tax->dev_stride = dstride;
-    std::vector<uint32_t> dev_rows(std::max<size_t>((size_t)n * dstride, 32), 0u);
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint32_t* src = &lin_sorted[(size_t)i * stride];
-        uint32_t* dst = &dev_rows[(size_t)i * dstride];
-        const uint32_t len = src[0] & 0xFF, shape = src[0] >> 8;
-        dst[0] = src[0];
-        for (uint32_t j = 0; j < len; ++j) {
-            const size_t k = (size_t)shape * tax->sc + j;
-            const uint32_t code = tax->h_codes[k];
-            const uint32_t rank = code & 0xFFFF, mar = code >> 16;
-            const uint32_t cid = cut_id(tax->h_cut[k]);
-            dst[2 + 2 * j] = src[1 + j];
-            dst[3 + 2 * j] = cid | (rank << BLU_PACK_CUT_BITS) |
-                             ((mar == BLU_MAR_NEVER_EQUAL ? BLU_PACK_NEVER : mar) << (BLU_PACK_CUT_BITS + BLU_PACK_CODE_BITS));
-        }
+    // device rows = the sorted host rows (header, node ids): 64 bytes for lineages of up to 15 levels; the per-level
+    // cutoff ids and rank codes depend on the shape only and live in a small table of their own (dev_codes)
+    tax->dev_stride = stride;
+    std::vector<uint32_t>& dev_rows = lin_sorted;
+    if (dev_rows.size() < 32) dev_rows.resize(32, 0u);
+    std::vector<uint32_t> dev_codes(std::max<size_t>((size_t)tax->n_shapes * tax->sc, 16), 0u);
+    for (size_t k = 0; k < (size_t)tax->n_shapes * tax->sc; ++k) {
+        const uint32_t code = tax->h_codes[k];
+        const uint32_t rank = code & 0xFFFF, mar = code >> 16;
+        dev_codes[k] = cut_id(tax->h_cut[k]) | (rank << BLU_PACK_CUT_BITS) |
+                       ((mar == BLU_MAR_NEVER_EQUAL ? BLU_PACK_NEVER : mar) << (BLU_PACK_CUT_BITS + BLU_PACK_CODE_BITS));
     }
     if (cutvals.size() >= (1u << BLU_PACK_CUT_BITS)) { delete tax; set_error("more than %u distinct cutoff values", (1u << BLU_PACK_CUT_BITS) - 1); return BLU_ERR_INVALID_ARG; }
     if (cutvals.empty()) cutvals.push_back(0.0);
@@ -353,10 +347,13 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         if (e == hipSuccess) tax->num_cus = prop.multiProcessorCount;
         size_t b_lin = dev_rows.size() * sizeof(uint32_t);
         size_t b_cut = cutvals.size() * sizeof(double);
+        size_t b_codes = dev_codes.size() * sizeof(uint32_t);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lin, b_lin);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lcp8, lcp8.size());
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_rmq, rmq.size());
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_cutvals, b_cut);
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_codes, b_codes);
+        if (e == hipSuccess) e = hipMemcpy(tax->d_codes, dev_codes.data(), b_codes, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_lin, dev_rows.data(), b_lin, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_lcp8, lcp8.data(), lcp8.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_rmq, rmq.data(), rmq.size(), hipMemcpyHostToDevice);
@@ -366,7 +363,7 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
             blu_taxonomy_destroy(tax);
             return BLU_ERR_HIP;
         }
-        tax->device_bytes = b_lin + lcp8.size() + rmq.size() + b_cut;
+        tax->device_bytes = b_lin + lcp8.size() + rmq.size() + b_cut + b_codes;
     }
     *out = tax;
     return BLU_OK;
@@ -380,6 +377,7 @@ void blu_taxonomy_destroy(blu_taxonomy* tax) {
         if (tax->d_lcp8) (void)hipFree(tax->d_lcp8);
         if (tax->d_rmq) (void)hipFree(tax->d_rmq);
         if (tax->d_cutvals) (void)hipFree(tax->d_cutvals);
+        if (tax->d_codes) (void)hipFree(tax->d_codes);
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
         if (tax->ws_count) (void)hipFree(tax->ws_count);
     }

@@ -127,6 +127,22 @@ def test_json_text_layout(tmp_path):
     assert raw == expected
 
 
+def test_more_than_three_decimals_keeps_the_f64_column(tmp_path):
+    """The pipeline hands perc_identity over as milli-percent only when every value is exactly k/1000; a table with
+    finer values keeps the f64 column, so a 4th-decimal difference still orders the hits (mod.rs:278-283)."""
+    (tmp_path / "t.json").write_text(json.dumps({"blutilsVersion": "x", "sourceDatabase": "y", "taxonomies": [
+        {"taxid": 10, "rank": "species", "numericLineage": "d__2;g__5;s__10", "textLineage": "d__bacteria;g__ba;s__ba-x", "accessions": []}]}))
+    (tmp_path / "b.tsv").write_text(
+        'q1\tACC_A.1\t10\t99.1234\t400\t0\t0\t1\t400\t1\t400\t1e-50\t700\n'
+        'q1\tACC_B.1\t10\t99.1233\t400\t0\t0\t1\t400\t1\t400\t1e-50\t700\n'
+        'q2\tACC_B.1\t10\t98.5\t400\t0\t0\t1\t400\t1\t400\t1e-50\t700\n')
+    for strategy, want in (("relaxed", 99.1234), ("cautious", 99.1233)):
+        got, _ = pipeline.build_consensus_identities(str(tmp_path / "b.tsv"), str(tmp_path / "t.json"), "bacteria", strategy)
+        by = {g["query"]: g["taxon"] for g in got}
+        assert by["q1"]["percIdentity"] == want and by["q1"]["reachedRank"] == "species"
+        assert by["q2"]["percIdentity"] == 98.5 and by["q2"]["singleMatch"] is True
+
+
 def test_cli_and_yaml(tmp_path, capsys):
     """`blu blastn build-consensus` arguments (commands.rs:105-143): stdout = compact JSON, file = pretty JSON with the
     extension forced; YAML carries the same values as JSON (numeric identifiers stay strings)."""
