@@ -156,8 +156,10 @@ __device__ __forceinline__ uint32_t packed_mar(uint32_t p) {
 // Stable sort by (len, pident, align_len, accession), then .first() (Cautious) or
 // .last() (Relaxed): find_multi_taxa_consensus.rs:39-68.  Candidates arrive in file
 // order, so Relaxed replaces the incumbent on ties (>=), Cautious keeps it (<).
-template <int STRAT>
-__device__ __forceinline__ bool key_better(uint32_t len, double pid, int aln, uint32_t acc, uint32_t blen, double bpid,
+// PK = double, or the milli-percent integer itself: k -> fl(k / 1000.0) is strictly increasing, so the integer
+// compares order the hits exactly as the reference's f64 compares do (and there is no NaN in that layout).
+template <int STRAT, typename PK>
+__device__ __forceinline__ bool key_better(uint32_t len, PK pid, int aln, uint32_t acc, uint32_t blen, PK bpid,
                                            int baln, uint32_t bacc) {
     const bool gt = (len > blen) | ((len == blen) & ((pid > bpid) | ((pid == bpid) & ((aln > baln) | ((aln == baln) & (acc > bacc))))));
     const bool eq = (len == blen) & (pid == bpid) & (aln == baln) & (acc == bacc);
@@ -209,8 +211,20 @@ __device__ __forceinline__ uint32_t shared_levels(const TaxDev& t, uint32_t lo, 
 // ===============================================================================
 struct Entry {            // one top-group row in LDS, 24 bytes
     uint32_t id, aln, acc, pq;    // id = engine row id (sorted position | length << BLU_ROW_BITS); pq = position in the segment | query-in-task << 8
-    double pid;
+    uint32_t p0, p1;              // pident: f64 bits (lo, hi), or the milli-percent integer in p0
 };
+template <bool PID32> struct PidKey { typedef double type; };
+template <> struct PidKey<true> { typedef uint32_t type; };
+template <bool PID32>
+__device__ __forceinline__ typename PidKey<PID32>::type entry_pid(const Entry& e) {
+    if constexpr (PID32) return e.p0;
+    else return __hiloint2double((int)e.p1, (int)e.p0);
+}
+template <bool PID32>
+__device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
+    if constexpr (PID32) return milli_to_f64(k);
+    else return k;
+}
 static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 
 #define META_SLOW 0x80000000u
@@ -358,8 +372,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             const uint32_t xt[4] = {vtax.x, vtax.y, vtax.z, vtax.w}, xa[4] = {valn.x, valn.y, valn.z, valn.w};
             const uint32_t xc[4] = {vacc.x, vacc.y, vacc.z, vacc.w};
             const uint32_t xm[4] = {vp01.x, vp01.y, vp01.z, vp01.w};   // PID32 layout
-            const double xp[4] = {__hiloint2double((int)vp01.y, (int)vp01.x), __hiloint2double((int)vp01.w, (int)vp01.z),
-                                  __hiloint2double((int)vp23.y, (int)vp23.x), __hiloint2double((int)vp23.w, (int)vp23.z)};
+            const uint32_t xlo[4] = {vp01.x, vp01.z, vp23.x, vp23.z}, xhi[4] = {vp01.y, vp01.w, vp23.y, vp23.w};   // f64 layout
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #ifdef BLU_EXP_NOLDS
@@ -369,7 +382,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
 #endif
                     Entry e;
                     e.id = xt[r]; e.aln = xa[r]; e.acc = xc[r]; e.pq = (sub4 + r) | (qi << 8);
-                    e.pid = PID32 ? milli_to_f64(xm[r]) : xp[r];
+                    e.p0 = PID32 ? xm[r] : xlo[r];
+                    e.p1 = PID32 ? 0u : xhi[r];
                     L.list[idx] = e;   // the row id carries the lineage length: phase 1 touches no taxonomy table
                     ++idx;
                 }
@@ -386,7 +400,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
 #ifdef BLU_EXP_P1ONLY
         {
             uint4 pa, pb;
-            pack_status(pa, pb, 2, (uint32_t)L.list[L.meta[lane] & 0xFF].pid + L.list[L.meta[lane] & 0xFF].id);
+            pack_status(pa, pb, 2, L.list[L.meta[lane] & 0xFF].p0 + L.list[L.meta[lane] & 0xFF].id);
             __builtin_amdgcn_wave_barrier();
             uint4* rec = reinterpret_cast<uint4*>(L.list);
             rec[2 * lane] = pa; rec[2 * lane + 1] = pb;
@@ -405,7 +419,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         const uint32_t row0 = (uint32_t)my_off;
         // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
         uint32_t mode = 3, r_len = 0, r_row = 0, r_pos = 0, r_hdr = 0, minlen = 0, d = 0, rec_kind = 0;
-        double r_pid = 0.0, max_pid = 0.0;
+        typedef typename PidKey<PID32>::type PK;
+        PK r_pid = 0, max_pid = 0;   // fold(0.0, max): find_multi_taxa_consensus.rs:182-185
         uint4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
         if ((uint32_t)lane < nq) {
             const uint64_t nrows = my_end - my_off;
@@ -423,9 +438,9 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                         err_pos = L.list[first + e].pq & 0xFF;
                     }
                 }
-                if (err == 0)
+                if (!PID32 && err == 0)
                     for (uint32_t e = 0; e < k; ++e) {
-                        const double p = L.list[first + e].pid;
+                        const double p = __hiloint2double((int)L.list[first + e].p1, (int)L.list[first + e].p0);
                         if (err == 0 && p != p) { err = BLU_ST_ERR_BAD_PIDENT; err_pos = L.list[first + e].pq & 0xFF; }
                     }
                 if (err) { pack_status(ra, rb, err, row0 + err_pos); rec_kind = 1; }
@@ -441,11 +456,12 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                         minlen = umin(minlen, len);
                         lo = umin(lo, pos);
                         hi = pos > hi ? pos : hi;
-                        max_pid = x.pid > max_pid ? x.pid : max_pid;
-                        const bool take = (e == 0) | key_better<STRAT>(len, x.pid, (int)x.aln, x.acc, b_len, r_pid, b_aln, b_acc);
+                        const PK xpid = entry_pid<PID32>(x);
+                        max_pid = xpid > max_pid ? xpid : max_pid;
+                        const bool take = (e == 0) | key_better<STRAT, PK>(len, xpid, (int)x.aln, x.acc, b_len, r_pid, b_aln, b_acc);
                         b_len = take ? len : b_len;
                         r_len = b_len;
-                        r_pid = take ? x.pid : r_pid;
+                        r_pid = take ? xpid : r_pid;
                         b_aln = take ? (int)x.aln : b_aln;
                         b_acc = take ? x.acc : b_acc;
                         r_row = take ? pos : r_row;
@@ -499,7 +515,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 const uint32_t* codes = t.codes + (uint64_t)(r_hdr >> 8) * t.cstride;
                 const uint4* codes4 = reinterpret_cast<const uint4*>(codes);
                 const uint32_t b = single ? len_ref : (agree ? minlen - 1 : d - 1);
-                const double ident = (single | agree) ? r_pid : max_pid;
+                const double ident = pid_f64<PID32>((single | agree) ? r_pid : max_pid);   // the one f64 the cutoff tests need
                 // linnaean_ranks.rs:174-212 + build_blast_consensus_identity.rs:67-82
                 uint64_t F = 0, A = 0;
                 uint32_t mar_level = BLU_NONE_U8, nF = 0;
@@ -736,13 +752,14 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             if (lane == 0) store_status(out, q, err_status, (uint32_t)start + err_row);
             continue;
         }
-        // NaN pident anywhere in the top group: second scan in file order (rare path kept simple)
-        {
+        // NaN pident anywhere in the top group: second scan in file order (rare path kept simple; the milli-percent
+        // layout has no NaN)
+        if (!PID32) {
             uint32_t nan_row = 0xFFFFFFFFu;
             for (uint32_t base = 0; base < n; base += WAVE) {
                 const uint32_t i = base + (uint32_t)lane;
                 const bool top = i < n && c_bs[i < n ? i : 0] == M;
-                const double pid = PID32 ? milli_to_f64(c_pm[top ? i : 0]) : c_pid[top ? i : 0];
+                const double pid = c_pid[top ? i : 0];
                 const uint64_t nm = __ballot(top && pid != pid);
                 if (nm) { nan_row = base + first_lane(nm); break; }
             }
