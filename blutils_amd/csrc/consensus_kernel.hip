@@ -228,6 +228,8 @@ __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
 static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 
 #define META_SLOW 0x80000000u
+#define LONG_SPAN (1u << 28)    // rows one bit-score descriptor of the worklist kernel covers
+#define TASK_SPAN (1ull << 28)   // rows one task's buffer descriptors cover
 #define CUT_LDS 512        // distinct cutoff values kept in LDS (4 KiB); larger tables are read from global memory
 #define ROW_MASK ((1u << BLU_ROW_BITS) - 1u)
 // the five hit columns are read exactly once per run: non-temporal loads keep them from displacing the
@@ -252,6 +254,9 @@ struct WaveLds {
     uint2 seg[WAVE + 4];        // {first row relative to the task's first row, row count (0 if > 64)}
 };
 
+#ifndef BLU_STEP_SETS
+#define BLU_STEP_SETS 2
+#endif
 #ifndef BLU_WAVES_PER_SIMD
 #define BLU_WAVES_PER_SIMD 1
 #endif
@@ -302,13 +307,14 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             if (my_off > my_end) my_off = my_end;
         }
         uint32_t fill = 0;   // wave-uniform: entries used in the LDS list
-        // Row offsets relative to the task's first row fit 32 bits (n_hits < 2^32).  One buffer descriptor per
-        // column, based at the task's first row: 32-bit lane offsets, no 64-bit VALU address math, and the
-        // hardware range check returns 0 for lanes that run past the end of the table.
+        bool in_span = true;
+        // One buffer descriptor per column, based at the task's first row and TASK_SPAN rows long: 32-bit lane byte
+        // offsets (< 2^31 also for the 8-byte column), no 64-bit VALU address math, and the hardware range check
+        // returns 0 for lanes past the end of the table or of the span.  A query that does not lie inside the span
+        // (a giant segment earlier in the task, or an offset table that is not ascending) goes to the worklist.
         const uint64_t task_start = rl_u64(my_off, 0);
-        const uint64_t rem = h.n_hits - task_start;
-        const uint32_t rem4 = (uint32_t)(rem * 4 > 0xFFFFFFFFull ? 0xFFFFFFFFull : rem * 4);
-        const uint32_t rem8 = (uint32_t)(rem * 8 > 0xFFFFFFFFull ? 0xFFFFFFFFull : rem * 8);
+        const uint64_t rem = (h.n_hits - task_start) < TASK_SPAN ? (h.n_hits - task_start) : TASK_SPAN;
+        const uint32_t rem4 = (uint32_t)(rem * 4), rem8 = (uint32_t)(rem * 8);
         const auto rs_bs = __builtin_amdgcn_make_buffer_rsrc((void*)(h.bitscore + task_start), 0, rem4, 0x00020000);
         const auto rs_tax = __builtin_amdgcn_make_buffer_rsrc((void*)(h.tax_row + task_start), 0, rem4, 0x00020000);
         const auto rs_aln = __builtin_amdgcn_make_buffer_rsrc((void*)(h.align_len + task_start), 0, rem4, 0x00020000);
@@ -319,36 +325,40 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         // (those go to the worklist in phase 2a) so that phase 1 simply finds no top row in them
         {
             const uint64_t nrows = my_end - my_off;
-            L.seg[lane] = make_uint2((uint32_t)(my_off - task_start), nrows <= WAVE ? (uint32_t)nrows : 0u);
+            in_span = my_off >= task_start && (my_end - task_start) <= TASK_SPAN;
+            L.seg[lane] = make_uint2((uint32_t)(my_off - task_start), (nrows <= WAVE && in_span) ? (uint32_t)nrows : 0u);
         }
         // ---------------- phase 1: 4 queries per step, 16 lanes per query, 4 consecutive rows per lane ----------------
         const uint32_t grp = (uint32_t)lane >> 4, sub4 = ((uint32_t)lane & 15u) * 4u;
-        for (uint32_t qb = 0; qb < nq; qb += 4) {
-            const uint32_t qi = qb + grp;                        // this lane's query (>= nq: empty slot of the table)
-            const uint2 sg = L.seg[qi];
-            const int left = (int)sg.y - (int)sub4;              // rows of the segment from this lane's first row on
-            const uint32_t voff = (sg.x + sub4) * 4u;
-            // lanes past the end of the segment issue nothing; their registers stay undefined and are masked by `left`
-            // below.  No VALU write touches a register with a load in flight, so nothing waits in front of the issue.
-            u32x4 vbs, vtax, vp01, vp23, valn, vacc;
-            if (left > 0) {
-                vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
-                vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, voff, 0, STREAM_AUX);
+        struct StepRegs { u32x4 vbs, vtax, vp01, vp23, valn, vacc; int left; uint32_t qi; };
+        // the loads of one step (4 queries); lanes past the end of the segment issue nothing: their registers stay
+        // undefined and are masked by `left`.  No VALU write touches a register with a load in flight, so nothing
+        // waits in front of the issue.
+        auto issue = [&](uint32_t qb, StepRegs& R) {
+            R.qi = qb + grp;                                     // this lane's query (>= nq: empty slot of the table)
+            const uint2 sg = L.seg[R.qi];
+            R.left = (int)sg.y - (int)sub4;                      // rows of the segment from this lane's first row on
+            // lanes past the end of the segment get an offset the descriptor's range check rejects: no memory
+            // access, no branch around the loads (so the wait counts below are exact)
+            const uint32_t voff = R.left > 0 ? (sg.x + sub4) * 4u : 0xFFFFFFF0u;
+            {
+                R.vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
+                R.vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, voff, 0, STREAM_AUX);
                 if (PID32) {
-                    vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff, 0, STREAM_AUX);   // four milli-percent values
-                    vp23 = vp01;
+                    R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff, 0, STREAM_AUX);   // four milli-percent values
+                    R.vp23 = R.vp01;
                 } else {
-                    vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u, 0, STREAM_AUX);
-                    vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u + 16u, 0, STREAM_AUX);
+                    R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u, 0, STREAM_AUX);
+                    R.vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u + 16u, 0, STREAM_AUX);
                 }
-                valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, voff, 0, STREAM_AUX);
-                vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, voff, 0, STREAM_AUX);
+                R.valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, voff, 0, STREAM_AUX);
+                R.vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, voff, 0, STREAM_AUX);
             }
-            // every loaded register is read here on every path (see the note on vmcnt at the loop head)
-            asm volatile("" ::"v"(vbs), "v"(vtax), "v"(vp01), "v"(vp23), "v"(valn), "v"(vacc));
-#ifdef BLU_EXP_NOREDUCE
-            continue;
-#endif
+        };
+        auto process = [&](const StepRegs& R) {
+            const int left = R.left;
+            const uint32_t qi = R.qi;
+            const u32x4 vbs = R.vbs, vtax = R.vtax, vp01 = R.vp01, vp23 = R.vp23, valn = R.valn, vacc = R.vacc;
             const int b0 = left > 0 ? (int)vbs.x : INT_MIN, b1 = left > 1 ? (int)vbs.y : INT_MIN;
             const int b2 = left > 2 ? (int)vbs.z : INT_MIN, b3 = left > 3 ? (int)vbs.w : INT_MIN;
             int M = imax(imax(b0, b1), imax(b2, b3));
@@ -389,6 +399,21 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 }
             }
             if (fits) fill = p3 + k3;
+        };
+        // BLU_STEP_SETS steps (4 queries each) have their loads issued together before the first one is processed:
+        // the wave keeps SETS x 5 KiB in flight instead of 5 KiB (its time is a chain of load latencies).
+        for (uint32_t qb = 0; qb < nq; qb += 4 * BLU_STEP_SETS) {
+            StepRegs R[BLU_STEP_SETS];
+#pragma unroll
+            for (int u = 0; u < BLU_STEP_SETS; ++u) issue(qb + 4 * u, R[u]);
+#pragma unroll
+            for (int u = 0; u < BLU_STEP_SETS; ++u) {
+                // every loaded register is read here on every path (otherwise hipcc parks a vmcnt(0) at the loop head)
+                asm volatile("" ::"v"(R[u].vbs), "v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc));
+#ifndef BLU_EXP_NOREDUCE
+                process(R[u]);
+#endif
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -426,7 +451,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             const uint64_t nrows = my_end - my_off;
             const uint32_t m = L.meta[lane];
             if (nrows == 0) { pack_status(ra, rb, BLU_ST_NO_HITS, 0xFFFFFFFFu); rec_kind = 1; }   // mod.rs:107-113
-            else if (nrows > WAVE || (m & META_SLOW)) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
+            else if (nrows > WAVE || !in_span || (m & META_SLOW)) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
             else {
                 const uint32_t first = m & 0xFFFF, k = (m >> 16) & 0xFF;
                 // parse errors first, in file order (find_single_query_consensus.rs:51-64), then NaN pident
@@ -681,19 +706,22 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
         // pass 1: top score
         // 16-byte loads, four per lane in flight (1024 rows per iteration); rows past the segment read as 0 from the
         // range-checked descriptor and are masked by index
-        const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)c_bs, 0, n * 4u, 0x00020000);
         int m = INT_MIN;
-        for (uint32_t base = 0; base < n; base += 1024) {
-            u32x4 v[4];
+        for (uint64_t sb = 0; sb < n; sb += LONG_SPAN) {   // descriptors cover LONG_SPAN rows: byte offsets stay below 2^32
+            const uint32_t ns = (n - sb) < LONG_SPAN ? (uint32_t)(n - sb) : LONG_SPAN;
+            const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(c_bs + sb), 0, ns * 4u, 0x00020000);
+            for (uint32_t base = 0; base < ns; base += 1024) {
+                u32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
+                for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t i0 = base + u * 256 + (uint32_t)lane * 4u;
-                m = imax(m, i0 < n ? (int)v[u].x : INT_MIN);
-                m = imax(m, i0 + 1 < n ? (int)v[u].y : INT_MIN);
-                m = imax(m, i0 + 2 < n ? (int)v[u].z : INT_MIN);
-                m = imax(m, i0 + 3 < n ? (int)v[u].w : INT_MIN);
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t i0 = base + u * 256 + (uint32_t)lane * 4u;
+                    m = imax(m, i0 < ns ? (int)v[u].x : INT_MIN);
+                    m = imax(m, i0 + 1 < ns ? (int)v[u].y : INT_MIN);
+                    m = imax(m, i0 + 2 < ns ? (int)v[u].z : INT_MIN);
+                    m = imax(m, i0 + 3 < ns ? (int)v[u].w : INT_MIN);
+                }
             }
         }
         const int M = wave_max_i32(m);
@@ -703,17 +731,20 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
         uint32_t l_lo = 0xFFFFFFFFu, l_hi = 0;   // span of this lane's top rows in the sorted lineage order
         int b_aln = 0;
         double b_pid = 0.0, l_maxpid = 0.0;
-        for (uint32_t base4 = 0; base4 < n && err_status == 0; base4 += 4 * WAVE) {
+        for (uint64_t sb = 0; sb < n && err_status == 0; sb += LONG_SPAN) {
+        const uint32_t ns = (n - sb) < LONG_SPAN ? (uint32_t)(n - sb) : LONG_SPAN;
+        const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(c_bs + sb), 0, ns * 4u, 0x00020000);
+        for (uint32_t base4 = 0; base4 < ns && err_status == 0; base4 += 4 * WAVE) {
           // the bit-scores of four 64-row chunks are fetched together; top rows are sparse, so most chunks end at the ballot
           int pre[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) pre[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_b, (base4 + u * WAVE + (uint32_t)lane) * 4u, 0, 0);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const uint32_t base = base4 + u * WAVE;
-            if (base >= n || err_status != 0) break;
+            const uint32_t base = (uint32_t)sb + base4 + u * WAVE;   // row index inside the segment
+            if (base4 + u * WAVE >= ns || err_status != 0) break;
             const uint32_t i = base + (uint32_t)lane;
-            const bool act = i < n;
+            const bool act = i < n && base4 + u * WAVE + (uint32_t)lane < ns;
             const bool top = act && pre[u] == M;
             const uint64_t mask = __ballot(top);
             if (!mask) continue;
@@ -748,6 +779,7 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
             l_maxpid = (top && pid > l_maxpid) ? pid : l_maxpid;
           }
         }
+        }
         if (err_status) {
             if (lane == 0) store_status(out, q, err_status, (uint32_t)start + err_row);
             continue;
@@ -756,12 +788,12 @@ __global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxD
         // layout has no NaN)
         if (!PID32) {
             uint32_t nan_row = 0xFFFFFFFFu;
-            for (uint32_t base = 0; base < n; base += WAVE) {
-                const uint32_t i = base + (uint32_t)lane;
+            for (uint64_t base = 0; base < n; base += WAVE) {
+                const uint64_t i = base + (uint32_t)lane;
                 const bool top = i < n && c_bs[i < n ? i : 0] == M;
                 const double pid = c_pid[top ? i : 0];
                 const uint64_t nm = __ballot(top && pid != pid);
-                if (nm) { nan_row = base + first_lane(nm); break; }
+                if (nm) { nan_row = (uint32_t)base + (uint32_t)first_lane(nm); break; }
             }
             if (nan_row != 0xFFFFFFFFu) {
                 if (lane == 0) store_status(out, q, BLU_ST_ERR_BAD_PIDENT, (uint32_t)start + nan_row);
