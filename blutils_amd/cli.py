@@ -6,15 +6,23 @@
 Same arguments as the reference's `blu blastn build-consensus`
 (ports/cli/src/cmds/blast/commands.rs:105-143, cmds/blast/mod.rs:104-146): without --blutils-out-file the
 document goes to stdout (compact JSON, as serde_json::to_writer prints it); with it, the extension is forced to
-the format's (write_blutils_output.rs:39-52) and JSON is pretty-printed.  The BLAST fan-out
-(`run-with-consensus`) and the DB builders are not part of this engine."""
+the format's (write_blutils_output.rs:39-52) and JSON is pretty-printed.
+
+    python -m blutils_amd.cli blastn build-tabular [BLU_RESULT|-] [-o OUT] [-i json|jsonl|yaml]
+
+= `blu blastn build-tabular` (commands.rs:145-161, parse_consensus_as_tabular/mod.rs:15).
+
+    python -m blutils_amd.cli cache-db TAX.json CACHE [-u]
+
+writes the binary cache of a taxonomies file (not in the reference CLI; pass CACHE as -t afterwards).  The BLAST
+fan-out (`run-with-consensus`) and the DB builders are not part of this engine."""
 from __future__ import annotations
 
 import argparse
 import os
 import sys
 
-from . import pipeline
+from . import pipeline, tabular
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -31,11 +39,28 @@ def build_parser() -> argparse.ArgumentParser:
     bc.add_argument("-u", "--use-taxid", action="store_true")
     bc.add_argument("--out-format", default="json", choices=["json", "jsonl", "yaml"])
     bc.add_argument("--device", type=int, default=0, help="HIP device ordinal (not in the reference CLI)")
+    bt = blastn.add_parser("build-tabular", help="blutils result document -> TSV")
+    bt.add_argument("blu_result", nargs="?", default="-")
+    bt.add_argument("-o", "--output-file")
+    bt.add_argument("-i", "--input-format", default="json", choices=["json", "jsonl", "yaml"])
+    cd = sub.add_parser("cache-db", help="binary cache of a *.blutils.json (pass it as --tax-file afterwards)")
+    cd.add_argument("tax_file")
+    cd.add_argument("cache_file")
+    cd.add_argument("-u", "--use-taxid", action="store_true")
     return ap
 
 
 def main(argv=None) -> int:
     args = build_parser().parse_args(argv)
+    if args.cmd == "cache-db":
+        pipeline.build_db_cache(args.tax_file, args.cache_file, args.use_taxid)
+        return 0
+    if args.sub == "build-tabular":
+        try:
+            tabular.parse_consensus_as_tabular(args.blu_result, args.output_file, args.input_format)
+        except tabular.TabularError as e:
+            raise SystemExit(str(e))
+        return 0
     custom = None
     if args.custom_taxon_cutoff_file:
         custom = pipeline.custom_taxon_from_file(args.custom_taxon_cutoff_file)        # CustomTaxon::from_file

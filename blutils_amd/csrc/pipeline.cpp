@@ -198,10 +198,119 @@ void add_lineage(Db& db, int64_t taxid, const std::string& lineage) {
     db.lin_off.push_back(db.lin_node.size());
 }
 
-// mod.rs:246-327 + domain/dtos/taxonomies_map.rs:6-32
+// ---- binary cache of the parsed taxonomies file ---------------------------------------------
+// What load_db produces from the `*.blutils.json` (mod.rs:246-327: only {taxid, numericLineage | textLineage} of each
+// entry is used), stored flat so a later run maps it instead of parsing ~100 MB of JSON per 300 k taxids:
+//   header | taxid i64[n] | lin_off u64[n+1] | lin_node u32[m] | lin_rank u16[m] | bad u8[n] |
+//   rank_off u32[r+1] | rank bytes | node_off u64[k+1] | node bytes      (sections padded to 8 bytes)
+// The header records which lineage flavour was interned (use_taxid) and an FNV-1a hash of everything after it.
+struct CacheHeader {
+    char magic[8];            // "BLUDBC01"
+    uint32_t version, use_taxid;
+    uint64_t n_tax, n_lin, n_ranks, n_nodes, rank_bytes, node_bytes, payload_bytes, payload_hash;
+};
+const char kCacheMagic[8] = {'B', 'L', 'U', 'D', 'B', 'C', '0', '1'};
+
+uint64_t fnv1a(const void* data, size_t n, uint64_t h = 1469598103934665603ull) {
+    // 8 bytes per step (a hash of 64-bit words, tail bytewise): this guards against truncation / bit rot, not malice
+    const unsigned char* p = (const unsigned char*)data;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 1099511628211ull; }
+    for (; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+
+size_t pad8(size_t n) { return (n + 7) & ~(size_t)7; }
+
+bool is_cache(const MappedFile& f) { return f.size >= sizeof(CacheHeader) && memcmp(f.data, kCacheMagic, 8) == 0; }
+
+int load_db_cache(const MappedFile& f, bool use_taxid, Db& db) {
+    CacheHeader h;
+    memcpy(&h, f.data, sizeof(h));
+    if (h.version != 1) { set_error("taxonomy cache: unsupported version %u", h.version); return BLU_ERR_PARSE; }
+    if ((h.use_taxid != 0) != use_taxid) {
+        set_error("taxonomy cache was built for %s lineages but the run asks for %s", h.use_taxid ? "numeric (-u)" : "text",
+                  use_taxid ? "numeric (-u)" : "text");
+        return BLU_ERR_INVALID_ARG;
+    }
+    const size_t sizes[9] = {h.n_tax * 8, (h.n_tax + 1) * 8, h.n_lin * 4, h.n_lin * 2, h.n_tax, (h.n_ranks + 1) * 4, h.rank_bytes,
+                             (h.n_nodes + 1) * 8, h.node_bytes};
+    size_t total = 0;
+    for (size_t x : sizes) total += pad8(x);
+    if (h.n_tax >= (1ull << BLU_ROW_BITS) || total != h.payload_bytes || sizeof(h) + total != f.size) {
+        set_error("taxonomy cache: size mismatch (truncated or not a cache file)");
+        return BLU_ERR_PARSE;
+    }
+    const char* p = f.data + sizeof(h);
+    if (fnv1a(p, total) != h.payload_hash) { set_error("taxonomy cache: checksum mismatch"); return BLU_ERR_PARSE; }
+    auto take = [&](void* dst, size_t bytes) { memcpy(dst, p, bytes); p += pad8(bytes); };
+    db.taxid.resize(h.n_tax); take(db.taxid.data(), sizes[0]);
+    db.lin_off.resize(h.n_tax + 1); take(db.lin_off.data(), sizes[1]);
+    db.lin_node.resize(h.n_lin); take(db.lin_node.data(), sizes[2]);
+    db.lin_rank.resize(h.n_lin); take(db.lin_rank.data(), sizes[3]);
+    db.bad.resize(h.n_tax); take(db.bad.data(), sizes[4]);
+    std::vector<uint32_t> roff(h.n_ranks + 1); take(roff.data(), sizes[5]);
+    const char* rbytes = p; p += pad8(sizes[6]);
+    std::vector<uint64_t> noff(h.n_nodes + 1); take(noff.data(), sizes[7]);
+    const char* nbytes = p;
+    // offsets are data: check them before they index anything
+    bool ok = db.lin_off[0] == 0 && db.lin_off[h.n_tax] == h.n_lin && roff[0] == 0 && roff[h.n_ranks] == h.rank_bytes &&
+              noff[0] == 0 && noff[h.n_nodes] == h.node_bytes;
+    for (uint64_t i = 0; ok && i < h.n_tax; ++i) ok = db.lin_off[i] <= db.lin_off[i + 1];
+    for (uint64_t i = 0; ok && i < h.n_ranks; ++i) ok = roff[i] <= roff[i + 1];
+    for (uint64_t i = 0; ok && i < h.n_nodes; ++i) ok = noff[i] <= noff[i + 1];
+    for (uint64_t i = 0; ok && i < h.n_lin; ++i) ok = db.lin_node[i] < h.n_nodes && db.lin_rank[i] < h.n_ranks;
+    if (!ok) { set_error("taxonomy cache: inconsistent offsets"); return BLU_ERR_PARSE; }
+    db.rank_raw.resize(h.n_ranks); db.rank_display.resize(h.n_ranks);
+    for (uint64_t i = 0; i < h.n_ranks; ++i) {
+        db.rank_raw[i].assign(rbytes + roff[i], roff[i + 1] - roff[i]);
+        db.rank_display[i] = canonical_display(db.rank_raw[i]);
+    }
+    db.node_ident.resize(h.n_nodes);
+    for (uint64_t i = 0; i < h.n_nodes; ++i) db.node_ident[i].assign(nbytes + noff[i], noff[i + 1] - noff[i]);
+    db.row_of.reserve(h.n_tax * 2);
+    for (uint64_t i = 0; i < h.n_tax; ++i) db.row_of.emplace(db.taxid[i], (uint32_t)i);   // first row wins for a duplicated taxid
+    return BLU_OK;
+}
+
+int write_db_cache(const Db& db, bool use_taxid, const char* path) {
+    CacheHeader h{};
+    memcpy(h.magic, kCacheMagic, 8);
+    h.version = 1; h.use_taxid = use_taxid ? 1 : 0;
+    h.n_tax = db.taxid.size(); h.n_lin = db.lin_node.size(); h.n_ranks = db.rank_raw.size(); h.n_nodes = db.node_ident.size();
+    std::vector<uint32_t> roff{0};
+    std::string rbytes, nbytes;
+    for (auto& r : db.rank_raw) { rbytes += r; roff.push_back((uint32_t)rbytes.size()); }
+    std::vector<uint64_t> noff{0};
+    for (auto& n : db.node_ident) { nbytes += n; noff.push_back(nbytes.size()); }
+    h.rank_bytes = rbytes.size(); h.node_bytes = nbytes.size();
+    std::string out;
+    auto put = [&](const void* src, size_t bytes) { out.append((const char*)src, bytes); out.append(pad8(bytes) - bytes, '\0'); };
+    put(db.taxid.data(), db.taxid.size() * 8);
+    put(db.lin_off.data(), db.lin_off.size() * 8);
+    put(db.lin_node.data(), db.lin_node.size() * 4);
+    put(db.lin_rank.data(), db.lin_rank.size() * 2);
+    put(db.bad.data(), db.bad.size());
+    put(roff.data(), roff.size() * 4);
+    put(rbytes.data(), rbytes.size());
+    put(noff.data(), noff.size() * 8);
+    put(nbytes.data(), nbytes.size());
+    h.payload_bytes = out.size();
+    h.payload_hash = fnv1a(out.data(), out.size());
+    std::string tmp = std::string(path) + ".tmp";
+    FILE* fp = fopen(tmp.c_str(), "wb");
+    if (!fp) { set_error("cannot write %s", tmp.c_str()); return BLU_ERR_IO; }
+    bool ok = fwrite(&h, sizeof(h), 1, fp) == 1 && (out.empty() || fwrite(out.data(), out.size(), 1, fp) == 1);
+    ok = (fclose(fp) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); set_error("cannot write %s", path); return BLU_ERR_IO; }
+    return BLU_OK;
+}
+
+// mod.rs:246-327 + domain/dtos/taxonomies_map.rs:6-32 (or the binary cache of the same content, see above)
 int load_db(const char* path, bool use_taxid, Db& db) {
     MappedFile f;
     if (!f.open(path)) { set_error("Taxonomies file not found: %s", path); return BLU_ERR_IO; }
+    if (is_cache(f)) return load_db_cache(f, use_taxid, db);
     Json j{f.data, f.data + f.size};
     if (!j.eat('{')) { set_error("taxonomies file is not a JSON object"); return BLU_ERR_PARSE; }
     bool found = false;
@@ -872,6 +981,14 @@ int blu_ingest_only(const char* blast_output_file, const char* taxonomies_file, 
 }
 
 // domain/dtos/taxon.rs:28-66: YAML (flat `key: value` lines) or JSON object with the eight fields
+int blu_db_cache_build(const char* taxonomies_file, int use_taxid, const char* cache_file) {
+    if (!taxonomies_file || !cache_file) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    Db db;
+    int rc = load_db(taxonomies_file, use_taxid != 0, db);
+    if (rc != BLU_OK) return rc;
+    return write_db_cache(db, use_taxid != 0, cache_file);
+}
+
 int blu_custom_taxon_from_file(const char* path, blu_cutoff_config* cfg) {
     if (!path || !cfg) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
     const char* dot = strrchr(path, '.');

@@ -51,6 +51,17 @@ def ingest_only(blast_output: str, taxonomies_file: str, use_taxid: bool = False
     return {f: getattr(st, f) for f, _ in PipelineStats._fields_}, ck.value
 
 
+def build_db_cache(taxonomies_file: str, cache_file: str, use_taxid: bool = False) -> None:
+    """Writes the binary cache of a `*.blutils.json` (include/blu_pipeline.h: blu_db_cache_build); pass the cache file
+    wherever a taxonomies file is expected."""
+    L = _bind()
+    L.blu_db_cache_build.restype = C.c_int
+    L.blu_db_cache_build.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+    rc = L.blu_db_cache_build(taxonomies_file.encode(), 1 if use_taxid else 0, cache_file.encode())
+    if rc != N.BLU_OK:
+        raise N.BluError(rc, "blu_db_cache_build")
+
+
 def custom_taxon_from_file(path: str) -> dict:
     """CustomTaxon::from_file (domain/dtos/taxon.rs:28-66)."""
     cfg = N.CutoffConfig()

@@ -70,6 +70,14 @@ void blu_free_text(char* text);
 int blu_ingest_only(const char* blast_output_file, const char* taxonomies_file, int use_taxid, blu_pipeline_stats* stats,
                     uint64_t* checksum);
 
+/* Binary cache of the taxonomies file.  The reference re-parses the `*.blutils.json` on every run
+ * (mod.rs:246-327, taxonomies_map.rs:6-32) and keeps only {taxid, numericLineage | textLineage}; this writes exactly
+ * that — interned lineages of the chosen flavour — as a flat file.  Wherever a `taxonomies_file` is taken
+ * (blu_build_consensus_identities, blu_ingest_only) a cache file is recognised by its magic and mapped instead of
+ * parsed; results are identical.  A cache built for the other lineage flavour is refused (BLU_ERR_INVALID_ARG), a
+ * truncated or altered one fails its checksum (BLU_ERR_PARSE). */
+int blu_db_cache_build(const char* taxonomies_file, int use_taxid, const char* cache_file);
+
 /* CustomTaxon::from_file (domain/dtos/taxon.rs:28-66): .yaml or .json with the eight cutoff fields. */
 int blu_custom_taxon_from_file(const char* path, blu_cutoff_config* cfg);
 

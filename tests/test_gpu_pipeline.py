@@ -105,6 +105,22 @@ def test_c1_files_through_the_pipeline(tmp_path, golden_dir, strategy, use_taxid
     assert n_found > 900
 
 
+def test_binary_taxonomy_cache_gives_the_same_document(tmp_path):
+    """the cache of the taxonomies file is a drop-in for the JSON (same interning, same records, same text)."""
+    tax = synth.make_taxonomy(2000, synth.SEEDS["C1"])
+    hits = synth.make_hits(tax, 1000, synth.SEEDS["C1"], 10, p_unmatched=0.002).numpy()
+    for use_taxid in (False, True):
+        bt, tj, _ = _write_inputs(tmp_path, tax, hits, use_taxid)
+        cache = str(tmp_path / f"tax.{int(use_taxid)}.blucache")
+        pipeline.build_db_cache(tj, cache, use_taxid)
+        a, _ = pipeline.build_consensus_identities(bt, tj, "bacteria", "relaxed", use_taxid, lenient=True, parse=False)
+        b, st = pipeline.build_consensus_identities(bt, cache, "bacteria", "relaxed", use_taxid, lenient=True, parse=False)
+        ja, jb = json.loads(a), json.loads(b)
+        for r in ja["results"] + jb["results"]:
+            r["runId"] = None                                                  # a fresh UUID per call
+        assert ja == jb and st["n_taxids"] == 2000
+
+
 def test_json_text_layout(tmp_path):
     """Byte layout of the JSON document = serde_json::to_string_pretty of BlutilsOutput{results, config: None}."""
     (tmp_path / "t.json").write_text(json.dumps({"blutilsVersion": "x", "sourceDatabase": "y", "taxonomies": [
