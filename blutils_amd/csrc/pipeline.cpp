@@ -792,6 +792,14 @@ extern "C" {
 int blu_build_consensus_identities(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
                                    const char* taxonomies_file, const blu_pipeline_params* params, char** out_text,
                                    size_t* out_len, blu_pipeline_stats* stats) {
+    return blu_build_consensus_identities_cfg(blast_output_file, headers, n_headers, taxonomies_file, params, nullptr, nullptr,
+                                              out_text, out_len, stats);
+}
+
+int blu_build_consensus_identities_cfg(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
+                                       const char* taxonomies_file, const blu_pipeline_params* params,
+                                       const char* run_id_text, const char* config_text, char** out_text, size_t* out_len,
+                                       blu_pipeline_stats* stats) {
     if (!blast_output_file || !taxonomies_file || !params || !out_text) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
     *out_text = nullptr;
     if (out_len) *out_len = 0;
@@ -879,13 +887,15 @@ int blu_build_consensus_identities(const char* blast_output_file, const char* co
     }
     const bool pretty = params->out_format == BLU_OUT_JSON;
     const bool doc = pretty || params->out_format == BLU_OUT_JSON_COMPACT;   // one {results, config} document
-    const std::string run_id = uuid_v4();
+    // write_blutils_output.rs:82-85: the config's run id, or a fresh one
+    const std::string run_id = (run_id_text && *run_id_text) ? std::string(run_id_text) : uuid_v4();
+    const std::string cfg = (config_text && *config_text) ? std::string(config_text) : std::string();
     Renderer R{db, ht, tax};
     std::string o;
     o.reserve(items.size() * 512);
     if (pretty) o += "{\n  \"results\": [";
     else if (doc) o += "{\"results\":[";
-    else o += "null\n";                                               // JSONL: the (absent) config line comes first
+    else { o += cfg.empty() ? "null" : cfg; o.push_back('\n'); }     // JSONL: the config line comes first
     if (params->out_format == BLU_OUT_YAML) {
         o.clear();
         o += items.empty() ? "results: []\n" : "results:\n";
@@ -896,7 +906,8 @@ int blu_build_consensus_identities(const char* blast_output_file, const char* co
             o += "  taxon:\n";
             R.taxon_yaml(o, (uint64_t)it.q, recs[(size_t)it.q]);
         }
-        o += "config: null\n";
+        if (cfg.empty()) o += "config: null\n";
+        else { o += "config:\n"; o += cfg; if (o.back() != '\n') o.push_back('\n'); }
     }
     if (params->out_format != BLU_OUT_YAML) {
         // records are independent: slices of the sorted list are rendered by worker threads and concatenated in order
@@ -936,8 +947,8 @@ int blu_build_consensus_identities(const char* blast_output_file, const char* co
         for (auto& po : parts) o += po;
     }
     if (params->out_format == BLU_OUT_YAML) {}
-    else if (pretty) { if (!items.empty()) o += "\n  "; o += "],\n  \"config\": null\n}"; }
-    else if (doc) o += "],\"config\":null}";
+    else if (pretty) { if (!items.empty()) o += "\n  "; o += "],\n  \"config\": "; o += cfg.empty() ? "null" : cfg; o += "\n}"; }
+    else if (doc) { o += "],\"config\":"; o += cfg.empty() ? "null" : cfg; o.push_back('}'); }
     st.t_render_s = now_s() - t0;
     blu_taxonomy_destroy(tax);
     char* buf = (char*)malloc(o.size() + 1);

@@ -74,9 +74,11 @@ def custom_taxon_from_file(path: str) -> dict:
 def build_consensus_identities(blast_output: str, taxonomies_file: str, taxon: str = "bacteria",
                                strategy: str = "relaxed", use_taxid: Optional[bool] = None,
                                custom_taxon_values: Optional[dict] = None, headers: Optional[Sequence[str]] = None,
-                               out_format: str = "json", device: int = 0, lenient: bool = False, parse: bool = True):
+                               out_format: str = "json", device: int = 0, lenient: bool = False, parse: bool = True,
+                               config=None):
     """Returns (results, stats).  results: the parsed `results` list (json) / list of records (jsonl), sorted by
-    query, or the raw text when parse=False."""
+    query, or the raw text when parse=False.  config: Some(BlastBuilder) of the run-with-consensus path
+    (blutils_amd.blast.BlastBuilder): its run id goes on every result and it is written as the document's config."""
     L = _bind()
     p = PipelineParams()
     p.cutoffs.taxon = N.TAXON[taxon]
@@ -98,8 +100,15 @@ def build_consensus_identities(blast_output: str, taxonomies_file: str, taxon: s
         n_hdr = len(enc)
     text, n = C.c_void_p(), C.c_size_t()
     st = PipelineStats()
-    rc = L.blu_build_consensus_identities(blast_output.encode(), C.cast(hdr_arr, C.c_void_p) if hdr_arr else None, n_hdr,
-                                          taxonomies_file.encode(), C.byref(p), C.byref(text), C.byref(n), C.byref(st))
+    L.blu_build_consensus_identities_cfg.restype = C.c_int
+    L.blu_build_consensus_identities_cfg.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_char_p, C.POINTER(PipelineParams),
+                                                     C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                                     C.POINTER(PipelineStats)]
+    run_id = str(config.run_id).encode() if config is not None else None
+    cfg_text = config.render(out_format).encode() if config is not None else None
+    rc = L.blu_build_consensus_identities_cfg(blast_output.encode(), C.cast(hdr_arr, C.c_void_p) if hdr_arr else None, n_hdr,
+                                              taxonomies_file.encode(), C.byref(p), run_id, cfg_text, C.byref(text),
+                                              C.byref(n), C.byref(st))
     if rc != N.BLU_OK:
         raise N.BluError(rc, "blu_build_consensus_identities")
     try:
@@ -115,5 +124,5 @@ def build_consensus_identities(blast_output: str, taxonomies_file: str, taxon: s
         import yaml
         return yaml.safe_load(raw)["results"], stats
     lines = raw.splitlines()
-    assert lines[0] == "null"   # the (absent) config line (write_blutils_output.rs:169-175)
+    assert config is not None or lines[0] == "null"   # the config line comes first (write_blutils_output.rs:169-175)
     return [json.loads(l) for l in lines[1:]], stats

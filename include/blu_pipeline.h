@@ -61,6 +61,15 @@ typedef struct blu_pipeline_stats {
 int blu_build_consensus_identities(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
                                    const char* taxonomies_file, const blu_pipeline_params* params, char** out_text,
                                    size_t* out_len, blu_pipeline_stats* stats);
+/* The same with Some(BlastBuilder) as `config` (run_blast_and_build_consensus/mod.rs:53-67 -> write_blutils_output):
+ * run_id_text = the config's run id (36 characters; NULL/"" = a fresh UUID), which every result carries
+ * (write_blutils_output.rs:82-104); config_text = the config already serialized for `out_format` at its place in the
+ * document (JSON: the value after "config": — for the pretty form with its inner lines indented by two spaces;
+ * JSONL: the first line; YAML: the block under `config:`), NULL/"" = null.  blutils_amd/blast.py produces it. */
+int blu_build_consensus_identities_cfg(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
+                                       const char* taxonomies_file, const blu_pipeline_params* params,
+                                       const char* run_id_text, const char* config_text, char** out_text, size_t* out_len,
+                                       blu_pipeline_stats* stats);
 void blu_free_text(char* text);
 
 /* The text-ingest half alone (no GPU): DB JSON + outfmt-6 TSV -> SoA columns, as blu_build_consensus_identities does it.
