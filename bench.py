@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--pident", default="milli", choices=["milli", "f64"],
                     help="hit-table layout: perc_identity as milli-percent u32 (lossless for BLAST's 3-decimal values, "
                          "20 B/hit) or as f64 (24 B/hit, the canonical layout of BASELINE.md)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one run (both kernels) in a HIP graph and time replays: for launch-bound sizes (C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
     args = ap.parse_args()
@@ -144,6 +146,17 @@ def main():
                                       f"restatement of the Rust path (oracle/blu_oracle.cpp), {cores} threads over "
                                       f"queries, {dt:.2f} s wall"}
             log(f"[bench] cpu baseline: {cpu_baseline['value']:.4f} Mq/s on {cores} threads ({dt:.2f}s)")
+
+    if args.graph:
+        # the run leaves its worklist counters as it found them, so the captured pair of kernels can be replayed
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            step()                                   # workspace allocation happens outside the capture
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            step()
+        step = graph.replay
 
     # ---- timed region
     for _ in range(args.warmup):

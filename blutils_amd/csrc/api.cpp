@@ -55,10 +55,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     if (hits->on_device) {
         HitsDev hd{hits->bitscore, hits->tax_row, hits->pident, hits->pident_milli, hits->align_len, hits->acc_rank, hits->seg_off,
                    hits->n_hits, hits->n_queries};
-        uint32_t* cur = tax->ws_count + 4 * tax->ws_parity;          // {queue length, -, take counter, -}
-        uint32_t* nxt = tax->ws_count + 4 * (tax->ws_parity ^ 1u);
-        tax->ws_parity ^= 1u;
-        return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus, tax->ws_worklist, cur, nxt);
+        return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count);
     }
 
     // host pointers: stage over PCIe, run, copy the records back (synchronous)
@@ -88,12 +85,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         HitsDev hd{(const int32_t*)d_bs, (const uint32_t*)d_tax, milli ? nullptr : (const double*)d_pid,
                    milli ? (const uint32_t*)d_pid : nullptr, (const int32_t*)d_aln,
                    (const uint32_t*)d_acc, (const uint64_t*)d_seg, hits->n_hits, hits->n_queries};
-        {
-            uint32_t* cur = tax->ws_count + 4 * tax->ws_parity;
-            uint32_t* nxt = tax->ws_count + 4 * (tax->ws_parity ^ 1u);
-            tax->ws_parity ^= 1u;
-            rc = launch_consensus(td, hd, params->strategy, (blu_result*)d_out, s, tax->device, tax->num_cus, tax->ws_worklist, cur, nxt);
-        }
+        rc = launch_consensus(td, hd, params->strategy, (blu_result*)d_out, s, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count);
         if (rc != BLU_OK) goto done;
         HIP_TRY(hipMemcpyAsync(out, d_out, nq * sizeof(blu_result), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));

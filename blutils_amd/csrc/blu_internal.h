@@ -69,9 +69,10 @@ struct HitsDev {
 };
 
 // launch wrapper implemented in consensus_kernel.hip
-// worklist: n_queries uint32 slots; work_count / next_count: this run's (already zero) and the next run's counter
+// worklist: n_queries uint32 slots; work_count: {queue length, blocks done}, zero between runs (the worklist kernel
+// leaves them so)
 int launch_consensus(const TaxDev& tax, const HitsDev& hits, int strategy, blu_result* out, void* stream,
-                     int device, int num_cus, uint32_t* worklist, uint32_t* work_count, uint32_t* next_count);
+                     int device, int num_cus, uint32_t* worklist, uint32_t* work_count);
 const char* consensus_kernel_name();
 void consensus_last_geometry(uint32_t* grid, uint32_t* block);
 
@@ -112,5 +113,4 @@ struct blu_taxonomy {
     mutable uint32_t* ws_worklist = nullptr;
     mutable uint32_t* ws_count = nullptr;
     mutable uint64_t ws_capacity = 0;
-    mutable uint32_t ws_parity = 0;           // which of the two worklist counters the next run uses
 };

@@ -228,6 +228,9 @@ __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
 static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 
 #define META_SLOW 0x80000000u
+#ifndef BLOCK_B
+#define BLOCK_B 256
+#endif
 #define LONG_SPAN (1u << 28)    // rows one bit-score descriptor of the worklist kernel covers
 #define TASK_SPAN (1ull << 28)   // rows one task's buffer descriptors cover
 #define CUT_LDS 512        // distinct cutoff values kept in LDS (4 KiB); larger tables are read from global memory
@@ -263,11 +266,8 @@ struct WaveLds {
 template <int STRAT, bool PID32>
 __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                        uint32_t* __restrict__ worklist,
-                                                                       uint32_t* __restrict__ work_count,
-                                                                       uint32_t* __restrict__ next_count) {
-    // two worklist counters, used alternately by consecutive runs on a handle: this run's is zero already (the
-    // previous run cleared it here), the other one is cleared now for the next run — no memset on the stream
-    if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0u;
+                                                                       uint32_t* __restrict__ work_count) {
+    // work_count = {queue length, blocks done, published length}: the first two are zero on entry and on exit
     __shared__ WaveLds s_lds[WAVES_A];
     // the distinct cutoff values of this (taxonomy, backbone): a few hundred doubles, read per level in phase 2c
     __shared__ double s_cut[CUT_LDS];
@@ -646,6 +646,19 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         __syncthreads();   // the staging area is the next task's list
 #endif
     }
+    // The last block to finish publishes the queue length for the worklist kernel and zeroes the two counters: a run
+    // leaves them as it found them — no memset between runs, and a captured graph of the two kernels can be replayed.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const uint32_t ticket = atomicAdd(work_count + 1, 1u);
+        if (ticket == gridDim.x - 1) {
+            const uint32_t n = __hip_atomic_load(work_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(work_count + 2, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(work_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(work_count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ===============================================================================
@@ -683,11 +696,11 @@ __device__ __forceinline__ int select_reference(bool valid, uint32_t len, uint32
 }
 
 template <int STRAT, bool PID32>
-__global__ __launch_bounds__(256) void blu_consensus_long_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
+__global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                  const uint32_t* __restrict__ worklist,
                                                                  const uint32_t* __restrict__ work_count) {
     const int lane = lane_id();
-    const uint32_t n_work = *work_count;
+    const uint32_t n_work = work_count[2];   // queue length published by the stream kernel's last block
     const uint32_t wave = blockIdx.x * (blockDim.x / WAVE) + __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     const uint32_t n_waves = gridDim.x * (blockDim.x / WAVE);
     for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
@@ -876,7 +889,7 @@ void consensus_last_geometry(uint32_t* grid, uint32_t* block) {
 
 template <int STRAT, bool PID32>
 static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hipStream_t s, int num_cus,
-                    uint32_t* worklist, uint32_t* work_count, uint32_t* next_count) {
+                    uint32_t* worklist, uint32_t* work_count) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blu_consensus_stream_kernel<STRAT, PID32>, BLOCK_A, 0) != hipSuccess || per_cu <= 0)
         per_cu = 2;
@@ -887,25 +900,26 @@ static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hip
     if (grid == 0) grid = 1;
     g_grid = grid;
     g_block = BLOCK_A;
-    hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, PID32>), dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count, next_count);
-    const uint32_t grid_b = (uint32_t)(num_cus > 0 ? num_cus : 256) * 8u;   // 32 waves per CU: the kernel is latency-bound per query
-    hipLaunchKernelGGL((blu_consensus_long_kernel<STRAT, PID32>), dim3(grid_b), dim3(256), 0, s, hits, tax, out, worklist, work_count);
+    hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, PID32>), dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count);
+    // 32 waves per CU: the kernel is latency-bound per query (block size 256 / 512 / 1024: 1.11 / 1.135 / 1.14 ms on C5)
+    const uint32_t grid_b = (uint32_t)(num_cus > 0 ? num_cus : 256) * (2048u / BLOCK_B);
+    hipLaunchKernelGGL((blu_consensus_long_kernel<STRAT, PID32>), dim3(grid_b), dim3(BLOCK_B), 0, s, hits, tax, out, worklist, work_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("kernel launch failed: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
     return BLU_OK;
 }
 
 int launch_consensus(const TaxDev& tax, const HitsDev& hits, int strategy, blu_result* out, void* stream, int device,
-                     int num_cus, uint32_t* worklist, uint32_t* work_count, uint32_t* next_count) {
+                     int num_cus, uint32_t* worklist, uint32_t* work_count) {
     (void)device;
     if (hits.n_queries == 0) return BLU_OK;
     const bool milli = hits.pident_milli != nullptr;
     if (strategy == BLU_RELAXED) {
-        if (milli) return launch_t<BLU_RELAXED, true>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count, next_count);
-        return launch_t<BLU_RELAXED, false>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count, next_count);
+        if (milli) return launch_t<BLU_RELAXED, true>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count);
+        return launch_t<BLU_RELAXED, false>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count);
     }
-    if (milli) return launch_t<BLU_CAUTIOUS, true>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count, next_count);
-    return launch_t<BLU_CAUTIOUS, false>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count, next_count);
+    if (milli) return launch_t<BLU_CAUTIOUS, true>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count);
+    return launch_t<BLU_CAUTIOUS, false>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count);
 }
 
 }  // namespace blu

@@ -236,3 +236,51 @@ def test_golden_vectors_through_the_gpu(golden_dir, strategy):
         assert mar == o["maxAllowedRank"] and bool(rec["flags"] & 1) == o["mutated"], (q, mar, o["maxAllowedRank"])
         if q >= len(zymo["cases"]) and strategy == doc["strategy"]:
             assert mar == exp["maxAllowedRank"] and bool(rec["flags"] & 1) == exp["mutated"]   # docs example: all fields
+
+
+def test_run_is_replayable_as_a_hip_graph():
+    """The two kernels of a run leave the worklist counters as they found them, so a captured run can be replayed on
+    new contents of the same buffers (and plain runs can follow graph replays on the same handle)."""
+    import torch
+    tax = synth.make_taxonomy(30000, synth.SEEDS["C5"], deep=True)
+    t = _engine_tax(tax, "bacteria")
+    tables = [synth.make_hits(tax, 20000, seed, None, zipf=(1.1, 1, 800), device="cuda") for seed in (5, 6, 7)]
+    nh = max(h.n_hits for h in tables)
+    static = {k: torch.zeros(nh if k != "seg_off" else 20001, dtype=dt, device="cuda")
+              for k, dt in (("seg_off", torch.int64), ("bitscore", torch.int32), ("tax_row", torch.int32),
+                            ("pident_milli", torch.int32), ("align_len", torch.int32), ("acc_rank", torch.int32))}
+    out = torch.zeros(32 * 20000, dtype=torch.uint8, device="cuda")
+
+    def load(h):
+        d = h.as_dict("milli")
+        d["tax_row"] = t.engine_rows(h.tax_row).contiguous()
+        for k in static:
+            static[k].zero_()
+            static[k][: d[k].numel()].copy_(d[k])
+        static["seg_off"][d["seg_off"].numel() - 1:] = int(d["seg_off"][-1])
+        return d
+
+    load(tables[0])
+    views = dict(static)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        engine.run_consensus_device(t, views, out, strategy="relaxed")     # warm-up (allocates the workspace)
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        engine.run_consensus_device(t, views, out, strategy="relaxed")
+    for h in tables + [tables[0]]:
+        load(h)
+        torch.cuda.synchronize()
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        got = engine.records_from_tensor(out)[: h.n_queries]
+        _assert_records_equal(got, H.columnar(tax, h.numpy(), "bacteria", "relaxed", threads=8))
+    # a plain run after the replays
+    d = tables[1].as_dict("milli")
+    d["tax_row"] = t.engine_rows(tables[1].tax_row).contiguous()
+    out2 = torch.zeros(32 * 20000, dtype=torch.uint8, device="cuda")
+    engine.run_consensus_device(t, d, out2, strategy="relaxed")
+    torch.cuda.synchronize()
+    _assert_records_equal(engine.records_from_tensor(out2), H.columnar(tax, tables[1].numpy(), "bacteria", "relaxed", threads=8))
