@@ -22,6 +22,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <iterator>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -138,6 +140,41 @@ struct Json {
 // ---------------------------------------------------------------------------------------------------------
 // taxonomy side
 // ---------------------------------------------------------------------------------------------------------
+// taxid -> row of the taxonomy table; open addressing, 16-byte entries (one cache line touched per lookup: the join
+// runs once per hit row).  First insertion wins for a duplicated taxid.
+struct TaxidMap {
+    struct E { int64_t key; uint32_t val, used; };
+    std::vector<E> tab = std::vector<E>(1024, E{0, 0, 0});
+    size_t n = 0;
+    static uint64_t mixk(int64_t k) { uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull; return x ^ (x >> 32); }
+    void rehash(size_t cap) {
+        std::vector<E> old(cap, E{0, 0, 0});
+        old.swap(tab);
+        for (const E& e : old) if (e.used) put(e.key, e.val);
+    }
+    void put(int64_t k, uint32_t v) {
+        const size_t m = tab.size() - 1;
+        size_t i = mixk(k) & m;
+        while (tab[i].used) { if (tab[i].key == k) return; i = (i + 1) & m; }
+        tab[i] = E{k, v, 1};
+    }
+    void reserve(size_t want) { size_t cap = tab.size(); while (cap < want * 2) cap *= 2; if (cap != tab.size()) rehash(cap); }
+    void emplace(int64_t k, uint32_t v) {
+        if ((n + 1) * 2 > tab.size()) rehash(tab.size() * 2);
+        const size_t m = tab.size() - 1;
+        size_t i = mixk(k) & m;
+        while (tab[i].used) { if (tab[i].key == k) return; i = (i + 1) & m; }
+        tab[i] = E{k, v, 1};
+        ++n;
+    }
+    uint32_t find_or(int64_t k, uint32_t missing) const {
+        const size_t m = tab.size() - 1;
+        size_t i = mixk(k) & m;
+        while (tab[i].used) { if (tab[i].key == k) return tab[i].val; i = (i + 1) & m; }
+        return missing;
+    }
+};
+
 struct Db {
     std::vector<int64_t> taxid;
     std::vector<uint64_t> lin_off{0};
@@ -149,7 +186,7 @@ struct Db {
     std::vector<std::string> node_ident;     // node id -> identifier string
     std::unordered_map<std::string, uint16_t> rank_ids;
     std::unordered_map<std::string, uint32_t> node_ids;   // key: Display(rank) + '\x1f' + identifier
-    std::unordered_map<int64_t, uint32_t> row_of;
+    TaxidMap row_of;
 };
 
 std::string canonical_display(const std::string& raw) {
@@ -268,7 +305,7 @@ int load_db_cache(const MappedFile& f, bool use_taxid, Db& db) {
     }
     db.node_ident.resize(h.n_nodes);
     for (uint64_t i = 0; i < h.n_nodes; ++i) db.node_ident[i].assign(nbytes + noff[i], noff[i + 1] - noff[i]);
-    db.row_of.reserve(h.n_tax * 2);
+    db.row_of.reserve(h.n_tax);
     for (uint64_t i = 0; i < h.n_tax; ++i) db.row_of.emplace(db.taxid[i], (uint32_t)i);   // first row wins for a duplicated taxid
     return BLU_OK;
 }
@@ -354,9 +391,9 @@ struct HitTable {
     std::vector<std::string> query_names;        // first-appearance order
     std::vector<uint64_t> seg_off;
     std::vector<int32_t> bitscore, align_len;
-    std::vector<uint32_t> tax_desc_row, acc_rank, acc_id;
+    std::vector<uint32_t> tax_desc_row, acc_rank;   // acc_rank: rank of the accession in byte order = index into `accessions`
     std::vector<double> pident;
-    std::vector<std::string> accessions;         // by acc_id
+    std::vector<std::string> accessions;         // sorted (String::cmp)
     uint64_t unmatched = 0;
 };
 
@@ -367,12 +404,37 @@ std::string strip_quotes(std::string_view v) {   // mod.rs:169-172 `.replace("\"
     return s;
 }
 
-// Parses one number the way the columns are typed (mod.rs:226-244); std::from_chars first (no allocation), strtod as
-// the fallback for forms from_chars refuses (leading '+', hex floats ...).
+// Parses one number the way the columns are typed (mod.rs:226-244).  Fast path for what BLAST prints — [-]digits[.digits]
+// with at most 15 significant digits: mantissa and 10^k are exact doubles and IEEE division rounds correctly (Clinger),
+// so the value is the one strtod / Rust's parser gives.  Everything else (exponents, '+', inf/nan, longer digit
+// strings) takes std::from_chars, then strtod for the forms from_chars refuses.  (libstdc++ 11's from_chars for
+// doubles goes through strtod with a locale switch: ~4 of them per row were most of the ingest time.)
 bool parse_f64(std::string_view v, double* out) {
     const char* b = v.data();
     const char* e = b + v.size();
     while (b < e && (*b == ' ')) ++b;
+    {
+        static const double p10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+        const char* p = b;
+        const bool neg = p < e && *p == '-';
+        if (neg) ++p;
+        uint64_t mant = 0;
+        int digits = 0, frac = 0;
+        const char* d0 = p;
+        while (p < e && (unsigned)(*p - '0') < 10u) { mant = mant * 10 + (unsigned)(*p - '0'); ++p; ++digits; }
+        const bool had_int = p > d0;
+        if (p < e && *p == '.') {
+            ++p;
+            const char* f0 = p;
+            while (p < e && (unsigned)(*p - '0') < 10u) { mant = mant * 10 + (unsigned)(*p - '0'); ++p; ++digits; ++frac; }
+            if (!had_int && p == f0) digits = 99;      // "." alone: not a number
+        } else if (!had_int) digits = 99;
+        if (p == e && digits <= 15) {
+            const double x = (double)mant / p10[frac];
+            *out = neg ? -x : x;
+            return true;
+        }
+    }
     auto r = std::from_chars(b, e, *out);
     if (r.ec == std::errc() && r.ptr == e) return true;
     std::string tmp(v);
@@ -381,22 +443,91 @@ bool parse_f64(std::string_view v, double* out) {
     return endp != tmp.c_str();
 }
 
-struct RawRow { std::string_view q, acc; uint32_t tax; int32_t bs, aln; double pid; };
+struct RawRow { uint32_t lq, la, tax; int32_t bs, aln; double pid; };   // lq / la: the chunk's own query / accession ids
+
+inline uint64_t hash_sv(std::string_view s) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (s.size() * 0xFF51AFD7ED558CCDull);
+    const char* p = s.data();
+    size_t n = s.size();
+    while (n >= 8) { uint64_t w; memcpy(&w, p, 8); h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29; p += 8; n -= 8; }
+    if (n) { uint64_t w = 0; memcpy(&w, p, n); h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 29; }
+    return h ^ (h >> 32);
+}
+
+// string_view -> dense id in first-appearance order; open addressing.  A slot holds the hash, the id and the first 16
+// bytes of the key, so a lookup of a short key (accessions, query ids) touches one cache line and never the text it
+// was first seen in (random reads into a mapped file of many GB: that, not the parsing, was the ingest's cost).  Keys
+// are views into the mapped file or into an arena that outlives the dictionary.
+struct SvDict {
+    struct Slot { uint64_t hash; uint32_t id1, len; char head[16]; };   // id1 = id + 1, 0 = empty
+    std::vector<Slot> slot;
+    std::vector<std::string_view> keys;      // by id
+    uint64_t mask;
+    explicit SvDict(size_t cap = 1024) : slot(cap, Slot{0, 0, 0, {0}}), mask(cap - 1) {}
+    void grow() {
+        std::vector<Slot> ns(slot.size() * 2, Slot{0, 0, 0, {0}});
+        const uint64_t nm = ns.size() - 1;
+        for (const Slot& e : slot) {
+            if (!e.id1) continue;
+            uint64_t i = e.hash & nm;
+            while (ns[i].id1) i = (i + 1) & nm;
+            ns[i] = e;
+        }
+        slot.swap(ns);
+        mask = nm;
+    }
+    uint32_t intern(std::string_view s, bool* is_new = nullptr) {
+        const uint64_t h = hash_sv(s);
+        const size_t hl = s.size() < 16 ? s.size() : 16;
+        uint64_t i = h & mask;
+        while (slot[i].id1) {
+            const Slot& e = slot[i];
+            if (e.hash == h && e.len == s.size() && memcmp(e.head, s.data(), hl) == 0 &&
+                (s.size() <= 16 || memcmp(keys[e.id1 - 1].data() + 16, s.data() + 16, s.size() - 16) == 0)) {
+                if (is_new) *is_new = false;
+                return e.id1 - 1;
+            }
+            i = (i + 1) & mask;
+        }
+        const uint32_t id = (uint32_t)keys.size();
+        Slot& e = slot[i];
+        e.hash = h; e.id1 = id + 1; e.len = (uint32_t)s.size();
+        memcpy(e.head, s.data(), hl);
+        keys.push_back(s);
+        if (is_new) *is_new = true;
+        if (keys.size() * 3 > slot.size() * 2) grow();
+        return id;
+    }
+};
 
 // One worker's share of the file: [begin, end) starts and ends on line boundaries.
 struct Chunk {
     const char* begin = nullptr;
     const char* end = nullptr;
     std::vector<RawRow> rows;
+    SvDict queries, accs;                    // this chunk's dictionaries (quotes already stripped)
+    std::deque<std::string> arena;           // owned copies of the fields that had quotes in them
+    std::vector<uint32_t> q_count;           // rows per local query
+    std::vector<uint32_t> qmap, amap;        // local id -> global query id / global accession rank
+    std::vector<uint64_t> at;                // local query -> next row slot in the grouped table
+    std::vector<std::string_view> acc_sorted;
     uint64_t unmatched = 0, first_line = 0, n_lines = 0;
     int rc = BLU_OK;
     std::string err;
+    std::string_view clean(std::string_view v) {   // mod.rs:169-172 `.replace("\"", "")`
+        if (!memchr(v.data(), '"', v.size())) return v;
+        arena.push_back(strip_quotes(v));
+        return arena.back();
+    }
 };
 
 void parse_chunk(Chunk& c, const Db& db, const char* path) {
     const char* p = c.begin;
     uint64_t line_no = 0;
     c.rows.reserve((size_t)(c.end - c.begin) / 96 + 16);
+    std::string_view last_q_raw, last_a_raw;
+    uint32_t last_q = 0, last_a = 0;
+    bool have_last = false;
     while (p < c.end) {
         const char* nl = (const char*)memchr(p, '\n', (size_t)(c.end - p));
         const char* le = nl ? nl : c.end;
@@ -433,9 +564,18 @@ void parse_chunk(Chunk& c, const Db& db, const char* path) {
                 c.rc = BLU_ERR_PARSE; c.err = msg; return;
             }
             RawRow r;
-            r.q = col[0]; r.acc = col[1];
-            auto ti = db.row_of.find((int64_t)taxid_f);
-            r.tax = ti == db.row_of.end() ? BLU_UNMATCHED_TAXID : ti->second;    // left join (mod.rs:72-76)
+            // rows of one query usually sit next to each other: the previous row's ids are tried before the dictionaries
+            if (!have_last || col[0] != last_q_raw) {
+                bool is_new = false;
+                last_q = c.queries.intern(c.clean(col[0]), &is_new);
+                if (is_new) c.q_count.push_back(0);
+                last_q_raw = col[0];
+            }
+            if (!have_last || col[1] != last_a_raw) { last_a = c.accs.intern(c.clean(col[1])); last_a_raw = col[1]; }
+            have_last = true;
+            ++c.q_count[last_q];
+            r.lq = last_q; r.la = last_a;
+            r.tax = db.row_of.find_or((int64_t)taxid_f, BLU_UNMATCHED_TAXID);    // left join (mod.rs:72-76)
             if (r.tax == BLU_UNMATCHED_TAXID) ++c.unmatched;
             r.bs = (int32_t)bs_t; r.aln = (int32_t)aln; r.pid = pid;
             c.rows.push_back(r);
@@ -443,11 +583,24 @@ void parse_chunk(Chunk& c, const Db& db, const char* path) {
         p = nl ? nl + 1 : c.end;
     }
     c.n_lines = line_no;
+    // this chunk's accessions in byte order (String::cmp), for the merge below
+    c.acc_sorted = c.accs.keys;
+    std::sort(c.acc_sorted.begin(), c.acc_sorted.end());
 }
 
-// a2 + a4 + a5: outfmt-6 text -> SoA columns.  The file is cut into line-aligned chunks parsed by worker threads
-// (numbers, tab scanning, the taxid join); dictionaries (queries in first-appearance order, accessions) and the
-// stable grouping are merged in file order afterwards, so the result does not depend on the thread count.
+template <class F>
+void parallel_for(unsigned n, unsigned nthreads, F&& f) {
+    if (nthreads <= 1 || n <= 1) { for (unsigned i = 0; i < n; ++i) f(i); return; }
+    std::vector<std::thread> pool;
+    for (unsigned i = 0; i < n; ++i) pool.emplace_back([&f, i]() { f(i); });
+    for (auto& th : pool) th.join();
+}
+
+// a2 + a4 + a5: outfmt-6 text -> SoA columns.  The file is cut into line-aligned chunks; each worker parses its
+// chunk (numbers, tab scanning, the taxid join) and interns query / accession strings in dictionaries of its own.
+// Afterwards only the DISTINCT strings are merged — queries in file order (first appearance decides a query's
+// position, mod.rs:192-208), accessions by a tree of sorted-list merges (their id is their rank in byte order) —
+// and the workers scatter their rows into the grouped table.  The result does not depend on the thread count.
 int load_hits(const char* path, const Db& db, HitTable& ht) {
     MappedFile f;
     if (!f.open(path)) { set_error("Unexpected error occurred on load table: %s", path); return BLU_ERR_IO; }
@@ -471,12 +624,11 @@ int load_hits(const char* path, const Db& db, HitTable& ht) {
         chunks[t].end = target;
         cur = target;
     }
-    if (nthreads == 1) parse_chunk(chunks[0], db, path);
-    else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back([&, t]() { parse_chunk(chunks[t], db, path); });
-        for (auto& th : pool) th.join();
-    }
+    const bool trace = getenv("BLU_INGEST_TRACE") != nullptr;
+    double tp = now_s();
+    auto lap = [&](const char* what) { if (trace) { const double t = now_s(); fprintf(stderr, "[ingest] %-22s %.3f s\n", what, t - tp); tp = t; } };
+    parallel_for(nthreads, nthreads, [&](unsigned t) { parse_chunk(chunks[t], db, path); });
+    lap("parse (parallel)");
     uint64_t lines_before = 0;
     size_t nh = 0;
     for (auto& c : chunks) {
@@ -485,53 +637,74 @@ int load_hits(const char* path, const Db& db, HitTable& ht) {
         nh += c.rows.size();
         ht.unmatched += c.unmatched;
     }
-    // dictionaries, in file order.  Strings keep their quotes stripped (mod.rs:169-172); rows of one query usually
-    // sit next to each other, so the previous row's ids are tried before the hash maps.
-    std::unordered_map<std::string, uint32_t> qids, accids;
-    std::vector<uint32_t> per_query, row_q(nh), row_acc(nh);
-    std::string_view last_q, last_a;
-    uint32_t last_qid = 0, last_aid = 0;
-    bool have_last = false;
-    size_t i = 0;
-    for (auto& c : chunks)
-        for (const RawRow& r : c.rows) {
-            if (!have_last || r.q != last_q) {
-                std::string q = strip_quotes(r.q);
-                auto it = qids.find(q);
-                if (it == qids.end()) { it = qids.emplace(q, (uint32_t)ht.query_names.size()).first; ht.query_names.push_back(std::move(q)); per_query.push_back(0); }
-                last_q = r.q; last_qid = it->second;
+    if (nh >= 0xFFFFFFFFull) { set_error("more than 2^32 - 2 hit rows in %s", path); return BLU_ERR_INVALID_ARG; }
+    // queries: the chunks' distinct names in file order -> global ids, and each chunk's first slot inside every segment
+    {
+        SvDict global(1u << 16);
+        std::vector<uint64_t> per_query;
+        std::vector<std::vector<uint64_t>> prior(nthreads);
+        for (unsigned t = 0; t < nthreads; ++t) {
+            Chunk& c = chunks[t];
+            c.qmap.resize(c.queries.keys.size());
+            prior[t].resize(c.queries.keys.size());
+            for (uint32_t l = 0; l < c.queries.keys.size(); ++l) {
+                bool is_new = false;
+                const uint32_t g = global.intern(c.queries.keys[l], &is_new);
+                if (is_new) { ht.query_names.emplace_back(c.queries.keys[l]); per_query.push_back(0); }
+                c.qmap[l] = g;
+                prior[t][l] = per_query[g];
+                per_query[g] += c.q_count[l];
             }
-            if (!have_last || r.acc != last_a) {
-                std::string a = strip_quotes(r.acc);
-                auto it = accids.find(a);
-                if (it == accids.end()) { it = accids.emplace(a, (uint32_t)ht.accessions.size()).first; ht.accessions.push_back(std::move(a)); }
-                last_a = r.acc; last_aid = it->second;
-            }
-            have_last = true;
-            row_q[i] = last_qid; row_acc[i] = last_aid;
-            ++per_query[last_qid];
-            ++i;
         }
-    // order-preserving accession ranks (String::cmp is bytewise)
-    std::vector<uint32_t> by_name(ht.accessions.size());
-    for (uint32_t k = 0; k < by_name.size(); ++k) by_name[k] = k;
-    std::sort(by_name.begin(), by_name.end(), [&](uint32_t a, uint32_t b) { return ht.accessions[a] < ht.accessions[b]; });
-    std::vector<uint32_t> rank_of(by_name.size());
-    for (uint32_t k = 0; k < by_name.size(); ++k) rank_of[by_name[k]] = k;
-    // stable grouping: queries in first-appearance order, rows of a query in file order (mod.rs:192-208)
-    const size_t nq = ht.query_names.size();
-    ht.seg_off.assign(nq + 1, 0);
-    for (size_t q = 0; q < nq; ++q) ht.seg_off[q + 1] = ht.seg_off[q] + per_query[q];
-    std::vector<uint64_t> at(ht.seg_off.begin(), ht.seg_off.end() - 1);
-    ht.bitscore.resize(nh); ht.align_len.resize(nh); ht.tax_desc_row.resize(nh); ht.acc_rank.resize(nh); ht.acc_id.resize(nh); ht.pident.resize(nh);
-    i = 0;
-    for (auto& c : chunks)
+        const size_t nq = ht.query_names.size();
+        ht.seg_off.assign(nq + 1, 0);
+        for (size_t q = 0; q < nq; ++q) ht.seg_off[q + 1] = ht.seg_off[q] + per_query[q];
+        for (unsigned t = 0; t < nthreads; ++t) {
+            Chunk& c = chunks[t];
+            c.at.resize(c.qmap.size());
+            for (uint32_t l = 0; l < c.qmap.size(); ++l) c.at[l] = ht.seg_off[c.qmap[l]] + prior[t][l];
+        }
+    }
+    lap("queries (merge)");
+    // accessions: tree of merges of the chunks' sorted lists; rank in the merged list = acc_rank = index into ht.accessions
+    {
+        std::vector<std::vector<std::string_view>> lists(nthreads);
+        for (unsigned t = 0; t < nthreads; ++t) lists[t] = chunks[t].acc_sorted;
+        for (unsigned step = 1; step < nthreads; step *= 2) {
+            std::vector<unsigned> heads;
+            for (unsigned i = 0; i + step < nthreads; i += 2 * step) heads.push_back(i);
+            parallel_for((unsigned)heads.size(), nthreads, [&](unsigned k) {
+                const unsigned i = heads[k];
+                std::vector<std::string_view> out;
+                out.reserve(lists[i].size() + lists[i + step].size());
+                std::set_union(lists[i].begin(), lists[i].end(), lists[i + step].begin(), lists[i + step].end(), std::back_inserter(out));
+                lists[i].swap(out);
+                std::vector<std::string_view>().swap(lists[i + step]);
+            });
+        }
+        const std::vector<std::string_view>& all = lists[0];
+        ht.accessions.resize(all.size());
+        parallel_for(nthreads, nthreads, [&](unsigned t) {
+            for (size_t k = all.size() * t / nthreads; k < all.size() * (t + 1) / nthreads; ++k) ht.accessions[k].assign(all[k]);
+            Chunk& c = chunks[t];
+            c.amap.resize(c.accs.keys.size());
+            for (uint32_t l = 0; l < c.accs.keys.size(); ++l)
+                c.amap[l] = (uint32_t)(std::lower_bound(all.begin(), all.end(), c.accs.keys[l]) - all.begin());
+        });
+    }
+    lap("accessions (merge)");
+    // stable grouping: queries in first-appearance order, rows of a query in file order (mod.rs:192-208); the chunks
+    // write disjoint slots
+    ht.bitscore.resize(nh); ht.align_len.resize(nh); ht.tax_desc_row.resize(nh); ht.acc_rank.resize(nh); ht.pident.resize(nh);
+    parallel_for(nthreads, nthreads, [&](unsigned t) {
+        Chunk& c = chunks[t];
         for (const RawRow& r : c.rows) {
-            const uint64_t d = at[row_q[i]]++;
-            ht.bitscore[d] = r.bs; ht.align_len[d] = r.aln; ht.tax_desc_row[d] = r.tax; ht.acc_rank[d] = rank_of[row_acc[i]];
-            ht.acc_id[d] = row_acc[i]; ht.pident[d] = r.pid;
-            ++i;
+            const uint64_t d = c.at[r.lq]++;
+            ht.bitscore[d] = r.bs; ht.align_len[d] = r.aln; ht.tax_desc_row[d] = r.tax; ht.acc_rank[d] = c.amap[r.la];
+            ht.pident[d] = r.pid;
         }
+    });
+    lap("scatter (parallel)");
     return BLU_OK;
 }
 
@@ -667,7 +840,7 @@ struct Renderer {
             b.identifier = db.node_ident[r.identifier_node];
             b.occurrences = 1;
             b.taxonomy = lineage_string(drow);
-            b.accessions.push_back(ht.accessions[ht.acc_id[row]]);
+            b.accessions.push_back(ht.accessions[ht.acc_rank[row]]);
             beans.push_back(std::move(b));
         } else {
             const int32_t M = ht.bitscore[row];
@@ -697,7 +870,7 @@ struct Renderer {
                     beans.push_back(std::move(b));
                     slot = &beans.back();
                 }
-                const std::string& acc = ht.accessions[ht.acc_id[i]];
+                const std::string& acc = ht.accessions[ht.acc_rank[i]];
                 if (slot->accessions.empty() || slot->accessions.back() != acc) slot->accessions.push_back(acc);   // extend + dedup()
                 slot->occurrences += 1;
             }
