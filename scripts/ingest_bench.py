@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--threads", default="1,4,16")
     ap.add_argument("--accessions", default="clustered", choices=["clustered", "uniform"])
     ap.add_argument("--dir", default="/tmp/blu_ingest_bench")
+    ap.add_argument("--pipeline", action="store_true", help="also run the whole use-case on the GPU (JSONL out) and print its stage times")
     args = ap.parse_args()
     from blutils_amd import pipeline
     os.makedirs(args.dir, exist_ok=True)
@@ -73,6 +74,13 @@ def main():
         phases = " | ".join(l.split("]")[1].strip() for l in p.stderr.splitlines() if l.startswith("[ingest]"))
         print(f"threads {th:2d}: {st['t_load_hits_s']:.3f} s = {rows / st['t_load_hits_s'] / 1e6:.2f} M rows/s = "
               f"{size / st['t_load_hits_s'] / 1e9:.2f} GB/s   (db load {st['t_load_db_s']:.3f} s)   [{phases}]")
+    if args.pipeline:
+        t0 = time.time()
+        text, st = pipeline.build_consensus_identities(bt, cache, "bacteria", "relaxed", out_format="jsonl", lenient=True, parse=False)
+        wall = time.time() - t0
+        print(f"pipeline: {wall:.2f} s wall for {st['n_queries']} queries / {st['n_hits']} rows -> {len(text) / 1e6:.0f} MB of JSONL "
+              f"({st['n_queries'] / wall / 1e6:.3f} Mq/s end to end): db {st['t_load_db_s']:.3f} s, ingest {st['t_load_hits_s']:.3f} s, "
+              f"engine incl. taxonomy build + PCIe staging {st['t_engine_s']:.3f} s, render {st['t_render_s']:.3f} s")
 
 
 if __name__ == "__main__":
