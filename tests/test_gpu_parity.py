@@ -284,3 +284,48 @@ def test_run_is_replayable_as_a_hip_graph():
     engine.run_consensus_device(t, d, out2, strategy="relaxed")
     torch.cuda.synchronize()
     _assert_records_equal(engine.records_from_tensor(out2), H.columnar(tax, tables[1].numpy(), "bacteria", "relaxed", threads=8))
+
+
+def test_hostile_offsets_and_row_ids_do_not_disturb_valid_queries():
+    """The C ABI takes offsets and row ids as data: a non-ascending or out-of-range offset table and garbage row ids
+    must neither fault nor change the records of the queries whose own segment is intact."""
+    rng = np.random.default_rng(17)
+    tax = synth.make_taxonomy(5000, synth.SEEDS["C2"])
+    hits = synth.make_hits(tax, 3000, synth.SEEDS["C2"], 20).numpy()
+    t = _engine_tax(tax, "bacteria")
+    rows = t.engine_rows(hits["tax_row"])
+    clean = engine.run_consensus_host(t, hits["seg_off"], hits["bitscore"], rows, hits["pident"], hits["align_len"],
+                                      hits["acc_rank"], "relaxed")
+    nq, nh = 3000, len(rows)
+    # 1. offsets: some entries swapped, some far past the table, some huge
+    seg = hits["seg_off"].copy()
+    touched = np.zeros(nq, bool)
+    for q in rng.choice(np.arange(1, nq - 1), 60, replace=False):
+        kind = int(rng.integers(0, 3))
+        seg[q] = [seg[q + 1] + 7, nh + 1000, 2 ** 40][kind] if kind else max(int(seg[q - 1]) - 3, 0)
+        touched[q - 1] = touched[q] = True
+    L = N.lib()
+    out = np.zeros(nq, dtype=engine.RESULT_DTYPE)
+    cols = [np.ascontiguousarray(hits["bitscore"], np.int32), np.ascontiguousarray(rows, np.uint32),
+            np.ascontiguousarray(hits["pident"], np.float64), np.ascontiguousarray(hits["align_len"], np.int32),
+            np.ascontiguousarray(hits["acc_rank"]).view(np.uint32)]
+    segc = np.ascontiguousarray(seg, np.uint64)
+    h = N.Hits(cols[0].ctypes.data, cols[1].ctypes.data, cols[2].ctypes.data, cols[3].ctypes.data, cols[4].ctypes.data,
+               segc.ctypes.data, nh, nq, 0, 0, None)
+    import ctypes as C
+    params = N.RunParams(N.STRATEGY["relaxed"], 0, None)
+    assert L.blu_consensus_run(t.handle, C.byref(h), C.byref(params), out.ctypes.data) == N.BLU_OK
+    ok = ~touched
+    assert out[ok].tobytes() == clean[ok].tobytes()
+    assert set(np.unique(out["status"])) <= {0, 1, 2, 16, 17, 18, 19, 20}
+    # 2. row ids: random bit patterns in 5 % of the rows (wrong length bits, positions past the table, the unmatched marker)
+    bad_rows = rows.copy()
+    idx = rng.choice(nh, nh // 20, replace=False)
+    bad_rows[idx] = rng.integers(0, 2 ** 32, len(idx), dtype=np.uint64).astype(np.uint32)
+    out2 = engine.run_consensus_host(t, hits["seg_off"], hits["bitscore"], bad_rows, hits["pident"], hits["align_len"],
+                                     hits["acc_rank"], "relaxed")
+    qid = np.searchsorted(hits["seg_off"], idx, side="right") - 1
+    intact = np.ones(nq, bool)
+    intact[qid] = False
+    assert intact.sum() > 300 and out2[intact].tobytes() == clean[intact].tobytes()
+    assert set(np.unique(out2["status"])) <= {0, 1, 2, 16, 17, 18, 19, 20}
