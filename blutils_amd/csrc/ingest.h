@@ -1,0 +1,67 @@
+// Types shared by the CPU ingest (pipeline.cpp) and the GPU ingest (ingest_gpu.hip).
+#ifndef BLU_INGEST_H
+#define BLU_INGEST_H
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace blu {
+
+// taxid -> row of the taxonomy table; open addressing, 16-byte entries (one cache line touched per lookup: the join
+// runs once per hit row).  First insertion wins for a duplicated taxid.
+struct TaxidMap {
+    struct E { int64_t key; uint32_t val, used; };
+    std::vector<E> tab = std::vector<E>(1024, E{0, 0, 0});
+    size_t n = 0;
+    static uint64_t mixk(int64_t k) { uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull; return x ^ (x >> 32); }
+    void rehash(size_t cap) {
+        std::vector<E> old(cap, E{0, 0, 0});
+        old.swap(tab);
+        for (const E& e : old) if (e.used) put(e.key, e.val);
+    }
+    void put(int64_t k, uint32_t v) {
+        const size_t m = tab.size() - 1;
+        size_t i = mixk(k) & m;
+        while (tab[i].used) { if (tab[i].key == k) return; i = (i + 1) & m; }
+        tab[i] = E{k, v, 1};
+    }
+    void reserve(size_t want) { size_t cap = tab.size(); while (cap < want * 2) cap *= 2; if (cap != tab.size()) rehash(cap); }
+    void emplace(int64_t k, uint32_t v) {
+        if ((n + 1) * 2 > tab.size()) rehash(tab.size() * 2);
+        const size_t m = tab.size() - 1;
+        size_t i = mixk(k) & m;
+        while (tab[i].used) { if (tab[i].key == k) return; i = (i + 1) & m; }
+        tab[i] = E{k, v, 1};
+        ++n;
+    }
+    uint32_t find_or(int64_t k, uint32_t missing) const {
+        const size_t m = tab.size() - 1;
+        size_t i = mixk(k) & m;
+        while (tab[i].used) { if (tab[i].key == k) return tab[i].val; i = (i + 1) & m; }
+        return missing;
+    }
+};
+
+// What the ingest hands to the engine and the renderer (a2 + a4 + a5 of SURVEY 8a).
+struct HitTable {
+    std::vector<std::string> query_names;        // first-appearance order
+    std::vector<uint64_t> seg_off;
+    std::vector<int32_t> bitscore, align_len;
+    std::vector<uint32_t> tax_desc_row, acc_rank;   // acc_rank: rank of the accession in byte order = index into `accessions`
+    std::vector<double> pident;
+    std::vector<std::string> accessions;         // sorted (String::cmp)
+    uint64_t unmatched = 0;
+};
+
+
+#define BLU_INGEST_FALLBACK (-100)   // load_hits_gpu: the file is not in the plain form the GPU parser handles; use the CPU path
+
+// outfmt-6 text -> grouped SoA columns on the GPU (ingest_gpu.hip).  Same result as the CPU ingest, bit for bit, for
+// files in the plain BLAST form (no quotes, no empty lines, numbers of <= 15 significant digits); anything else returns
+// BLU_INGEST_FALLBACK with the reason in *why and the caller parses on the CPU.
+int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int device, HitTable& ht, std::string* why);
+
+}  // namespace blu
+#endif

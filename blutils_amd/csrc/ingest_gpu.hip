@@ -1,0 +1,640 @@
+// GPU ingest of BLAST outfmt-6 text ("GPU-side parser"): the whole file goes to HBM once and comes back as
+// the grouped SoA columns the engine reads.  It produces exactly what the CPU ingest in pipeline.cpp produces
+// (reference: build_consensus_identities/mod.rs:134-244,329-373 — 13 tab-separated columns, rows regrouped by query
+// in first-appearance order with file order kept inside a query, bit_score truncated toward zero, left join on the
+// taxid), for files in the plain form BLAST writes; any other file (quotes, empty lines, odd numbers) is handed back
+// to the CPU path untouched (BLU_INGEST_FALLBACK).
+//
+// Stages (all on the handle's device, default stream):
+//   1. line index      newline count per 4 KiB tile -> exclusive scan -> line starts
+//   2. parse           one thread per line: tab scan over aligned 16-byte loads, decimal fast path for the four numeric
+//                      columns (mantissa <= 15 digits and |exp10| <= 22: one IEEE operation, so the value is strtod's),
+//                      taxid -> taxonomy row through the uploaded open-addressing map, two 64-bit hashes of the query
+//                      and accession fields
+//   3. dictionaries    open-addressing tables keyed by hash (insert = CAS on the hash + atomicMin of the row), finalised
+//                      with length + first 12 key bytes; every row then verifies its own text against its slot (a
+//                      mismatch = two strings with one 64-bit hash -> fallback), so ids are exact, not probabilistic
+//   4. ids             queries numbered by first row (radix sort of the distinct entries); accessions ranked in byte
+//                      order on the host (only the distinct strings travel) and the ranks uploaded
+//   5. grouping        stable radix sort by query id unless the file is grouped already; gathers; segment offsets
+// Library primitives (hipcub scan / radix sort) are used for the bookkeeping; the parsing and dictionary kernels are
+// written here.  HBM-bound byte work: no MFMA.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <vector>
+
+#include "blu_consensus.h"
+#include "blu_internal.h"
+#include "ingest.h"
+
+namespace blu {
+namespace {
+
+enum : uint32_t {
+    FB_EMPTY_LINE = 1, FB_COLUMNS = 2, FB_QUOTE = 4, FB_NUMBER = 8, FB_RANGE = 16, FB_HASH_COLLISION = 32, FB_TABLE_FULL = 64,
+};
+
+struct Slot {            // 32 bytes
+    unsigned long long hash;   // 0 = empty
+    uint32_t first_row;        // smallest row index holding this key
+    uint32_t id;               // query id / accession rank
+    uint32_t len;
+    unsigned char head[12];
+};
+
+struct DevTaxidMap { const TaxidMap::E* tab; uint64_t mask; };
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("GPU ingest: %s failed: %s", #x, hipGetErrorString(e_)); rc = BLU_ERR_HIP; goto done; } } while (0)
+
+// ---- 1. line index ---------------------------------------------------------------------------------------
+constexpr int TILE_THREADS = 256;
+constexpr uint64_t TILE_BYTES = TILE_THREADS * 16;
+
+__device__ __forceinline__ uint32_t nl_mask16(const uint4 v, uint64_t base, uint64_t size) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t c = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
+        if (c == '\n' && base + k < size) m |= 1u << k;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void count_newlines(const uint4* __restrict__ text, uint64_t size, uint32_t* __restrict__ tile_count) {
+    const uint64_t base = ((uint64_t)blockIdx.x * TILE_THREADS + threadIdx.x) * 16;
+    uint32_t c = 0;
+    if (base < size) c = __popc(nl_mask16(text[base / 16], base, size));
+    typedef hipcub::BlockReduce<uint32_t, TILE_THREADS> BR;
+    __shared__ typename BR::TempStorage tmp;
+    const uint32_t total = BR(tmp).Sum(c);
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void write_line_starts(const uint4* __restrict__ text, uint64_t size, const uint32_t* __restrict__ tile_base,
+                                                                  uint64_t* __restrict__ line_start) {
+    const uint64_t base = ((uint64_t)blockIdx.x * TILE_THREADS + threadIdx.x) * 16;
+    uint32_t m = 0;
+    if (base < size) m = nl_mask16(text[base / 16], base, size);
+    typedef hipcub::BlockScan<uint32_t, TILE_THREADS> BS;
+    __shared__ typename BS::TempStorage tmp;
+    uint32_t before = 0;
+    BS(tmp).ExclusiveSum((uint32_t)__popc(m), before);
+    uint64_t k = (uint64_t)tile_base[blockIdx.x] + before;
+    while (m) {
+        const int b = __ffs(m) - 1;
+        m &= m - 1;
+        line_start[++k] = base + b + 1;     // line k+1 starts after newline k
+    }
+}
+
+// ---- 2. parse ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t taxid_lookup(const DevTaxidMap& t, long long k) {
+    unsigned long long x = (unsigned long long)k * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 32;
+    uint64_t i = x & t.mask;
+    for (;;) {
+        const TaxidMap::E e = t.tab[i];
+        if (!e.used) return BLU_UNMATCHED_TAXID;
+        if (e.key == k) return e.val;
+        i = (i + 1) & t.mask;
+    }
+}
+
+__device__ const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+struct NumState {
+    unsigned long long mant;
+    int digits, frac, exp10, exp_digits;
+    bool neg, exp_neg, exp_sign, seen_dot, seen_exp, bad, any;
+    __device__ void reset() { mant = 0; digits = frac = exp10 = exp_digits = 0; neg = exp_neg = exp_sign = seen_dot = seen_exp = bad = any = false; }
+    __device__ void feed(uint32_t c, bool first) {
+        if (c - '0' < 10u) {
+            if (seen_exp) { exp10 = exp10 * 10 + (int)(c - '0'); if (++exp_digits > 3) bad = true; }
+            else { mant = mant * 10 + (c - '0'); if (mant != 0 || seen_dot) ++digits; if (seen_dot) ++frac; any = true; }
+        } else if (c == '-' && first) neg = true;
+        else if (c == '.' && !seen_dot && !seen_exp) seen_dot = true;
+        else if ((c == 'e' || c == 'E') && any && !seen_exp) seen_exp = true;
+        else if ((c == '-' || c == '+') && seen_exp && exp_digits == 0 && !exp_sign) { exp_sign = true; exp_neg = c == '-'; }
+        else bad = true;
+    }
+    // the value strtod gives, or bad: mantissa and 10^k exact, one correctly rounded operation (Clinger's fast path)
+    __device__ bool value(double* out) const {
+        if (bad || !any || digits > 15 || frac > 300 || (seen_exp && exp_digits == 0)) return false;
+        const int e = (exp_neg ? -exp10 : exp10) - frac;
+        if (e < -22 || e > 22) return false;
+        const double m = (double)mant;
+        const double x = e < 0 ? m / P10[-e] : m * P10[e];
+        *out = neg ? -x : x;
+        return true;
+    }
+};
+
+__device__ __forceinline__ unsigned long long hash_step(unsigned long long h, uint32_t c) { return (h ^ c) * 1099511628211ull; }
+__device__ __forceinline__ unsigned long long hash_finish(unsigned long long h, uint32_t len) {
+    h ^= (unsigned long long)len * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    return h ? h : 1ull;   // 0 marks an empty slot
+}
+
+struct RowOut {
+    unsigned long long* qh; unsigned long long* ah;     // hashes of the query / accession fields
+    unsigned long long* qpos; unsigned long long* apos;  // field offset | length << 44
+    uint32_t* tax; double* pid; int32_t* aln; int32_t* bs;
+};
+
+__global__ __launch_bounds__(256) void parse_rows(const unsigned char* __restrict__ text, const uint64_t* __restrict__ line_start, uint32_t n_rows,
+                                                  DevTaxidMap taxmap, RowOut o, uint32_t* __restrict__ flags,
+                                                  unsigned long long* __restrict__ n_unmatched) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint64_t p = line_start[i];
+    uint64_t e = line_start[i + 1] - 1;                 // the newline (or one past the end of a last line without one)
+    if (e > p && text[e - 1] == '\r') --e;
+    if (e <= p) { atomicOr(flags, FB_EMPTY_LINE); return; }
+    int col = 0;
+    uint64_t fstart = p;                                // start of the current field
+    unsigned long long h = 1469598103934665603ull;
+    NumState num;
+    num.reset();
+    double v_tax = 0, v_pid = 0, v_aln = 0, v_bs = 0;
+    uint32_t fb = 0;
+    auto end_field = [&](uint64_t fend) {
+        const uint64_t len = fend - fstart;
+        if (col == 0) { o.qh[i] = hash_finish(h, (uint32_t)len); o.qpos[i] = fstart | (len << 44); if (len >= (1u << 20)) fb |= FB_COLUMNS; }
+        else if (col == 1) { o.ah[i] = hash_finish(h, (uint32_t)len); o.apos[i] = fstart | (len << 44); if (len >= (1u << 20)) fb |= FB_COLUMNS; }
+        else if (col == 2) { if (!num.value(&v_tax)) fb |= FB_NUMBER; }
+        else if (col == 3) { if (!num.value(&v_pid)) fb |= FB_NUMBER; }
+        else if (col == 4) { if (!num.value(&v_aln)) fb |= FB_NUMBER; }
+        else if (col == 12) { if (!num.value(&v_bs)) fb |= FB_NUMBER; }
+        ++col;
+        fstart = fend + 1;
+        h = 1469598103934665603ull;
+        num.reset();
+    };
+    // aligned 16-byte loads; bytes outside [p, e) are skipped
+    for (uint64_t a = p & ~15ull; a < e && col < 13; a += 16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(text + a);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint64_t q = a + k;
+            if (q < p || q >= e || col >= 13) continue;
+            const uint32_t c = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
+            if (c == '\t') { end_field(q); continue; }
+            if (col <= 1) { h = hash_step(h, c); if (c == '"') fb |= FB_QUOTE; }
+            else if (col <= 4 || col == 12) num.feed(c, q == fstart);
+        }
+    }
+    if (col < 13) end_field(e);                         // the last field ends with the line
+    if (col < 13) fb |= FB_COLUMNS;
+    if (fb) { atomicOr(flags, fb); return; }
+    // mod.rs:184 AnyValue::Float64 -> try_extract::<i64> (truncation); the engine columns are 32-bit
+    const double bs_t = trunc(v_bs);
+    if (!(bs_t >= -2147483648.0 && bs_t <= 2147483647.0) || !(v_aln >= -2147483648.0 && v_aln <= 2147483647.0) ||
+        !(v_tax >= -9.2e18 && v_tax <= 9.2e18)) { atomicOr(flags, FB_RANGE); return; }
+    const uint32_t row = taxid_lookup(taxmap, (long long)v_tax);   // left join (mod.rs:72-76)
+    if (row == BLU_UNMATCHED_TAXID) atomicAdd(n_unmatched, 1ull);
+    o.tax[i] = row; o.pid[i] = v_pid; o.aln[i] = (int32_t)v_aln; o.bs[i] = (int32_t)bs_t;
+}
+
+// ---- 3. dictionaries ---------------------------------------------------------------------------------------------
+__global__ void count_run_heads(const unsigned long long* __restrict__ h, uint32_t n, unsigned long long* __restrict__ count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool head = i < n && (i == 0 || h[i] != h[i - 1]);
+    const unsigned long long m = __ballot(head);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
+__global__ void dict_init(Slot* __restrict__ tab, uint64_t n_slots) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_slots) { Slot e; memset(&e, 0, sizeof e); e.first_row = 0xFFFFFFFFu; tab[s] = e; }
+}
+
+// insert = CAS on the hash, atomicMin on the row; only_heads: rows whose hash equals the previous row's are skipped
+__global__ void dict_insert(const unsigned long long* __restrict__ h, uint32_t n, Slot* __restrict__ tab, uint64_t mask, bool only_heads,
+                            uint32_t* __restrict__ n_keys, uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = h[i];
+    if (only_heads && i > 0 && h[i - 1] == key) return;
+    uint64_t s = key & mask;
+    for (uint32_t probes = 0; probes < 8192; ++probes) {
+        unsigned long long cur = __hip_atomic_load(&tab[s].hash, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0) {
+            cur = atomicCAS(&tab[s].hash, 0ull, key);
+            if (cur == 0) { atomicAdd(n_keys, 1u); cur = key; }
+        }
+        if (cur == key) { atomicMin(&tab[s].first_row, i); return; }
+        s = (s + 1) & mask;
+    }
+    atomicOr(flags, FB_TABLE_FULL);
+}
+
+// occupied slots: key length and first bytes from the text of their first row; list of (first_row, slot)
+__global__ void dict_finalize(Slot* __restrict__ tab, uint64_t n_slots, const unsigned char* __restrict__ text,
+                              const unsigned long long* __restrict__ pos, uint32_t* __restrict__ list_row, uint32_t* __restrict__ list_slot,
+                              uint32_t* __restrict__ cursor) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots || tab[s].hash == 0) return;
+    const unsigned long long fp = pos[tab[s].first_row];
+    const uint64_t off = fp & ((1ull << 44) - 1);
+    const uint32_t len = (uint32_t)(fp >> 44);
+    tab[s].len = len;
+    for (uint32_t k = 0; k < 12; ++k) tab[s].head[k] = k < len ? text[off + k] : 0;
+    const uint32_t at = atomicAdd(cursor, 1u);
+    list_row[at] = tab[s].first_row;
+    list_slot[at] = (uint32_t)s;
+}
+
+__global__ void dict_assign_ids(Slot* __restrict__ tab, const uint32_t* __restrict__ slot_of_rank, const uint32_t* __restrict__ id_of_rank, uint32_t n) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) tab[slot_of_rank[r]].id = id_of_rank ? id_of_rank[r] : r;
+}
+
+// every row: find its slot, compare its own text with the slot's key (exact ids), write the id
+__global__ void dict_lookup(const unsigned long long* __restrict__ h, const unsigned long long* __restrict__ pos, uint32_t n,
+                            const Slot* __restrict__ tab, uint64_t mask, const unsigned char* __restrict__ text,
+                            const unsigned long long* __restrict__ pos_all, uint32_t* __restrict__ id_out, uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = h[i];
+    uint64_t s = key & mask;
+    for (;;) {                                           // present: it was inserted (or merged into a run) above
+        const unsigned long long cur = tab[s].hash;
+        if (cur == key) break;
+        if (cur == 0) { atomicOr(flags, FB_TABLE_FULL); id_out[i] = 0; return; }
+        s = (s + 1) & mask;
+    }
+    const Slot sl = tab[s];
+    const uint64_t off = pos[i] & ((1ull << 44) - 1);
+    const uint32_t len = (uint32_t)(pos[i] >> 44);
+    bool same = len == sl.len;
+    for (uint32_t k = 0; same && k < 12 && k < len; ++k) same = text[off + k] == sl.head[k];
+    if (same && len > 12 && sl.first_row != i) {
+        const uint64_t roff = pos_all[sl.first_row] & ((1ull << 44) - 1);
+        for (uint32_t k = 12; same && k < len; ++k) same = text[off + k] == text[roff + k];
+    }
+    if (!same) atomicOr(flags, FB_HASH_COLLISION);
+    id_out[i] = sl.id;
+}
+
+__global__ void gather_pos(const unsigned long long* __restrict__ pos, const uint32_t* __restrict__ rows, uint32_t n, unsigned long long* __restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) out[r] = pos[rows[r]];
+}
+
+// first 16 bytes of each listed field as two big-endian words: integer compares order them like memcmp
+__global__ void gather_key16(const unsigned long long* __restrict__ pos, uint32_t n, const unsigned char* __restrict__ text,
+                             unsigned long long* __restrict__ k0, unsigned long long* __restrict__ k1) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint64_t off = pos[r] & ((1ull << 44) - 1);
+    const uint32_t len = (uint32_t)(pos[r] >> 44);
+    unsigned long long a = 0, b = 0;
+    for (uint32_t k = 0; k < 8; ++k) a = (a << 8) | (k < len ? text[off + k] : 0);
+    for (uint32_t k = 8; k < 16; ++k) b = (b << 8) | (k < len ? text[off + k] : 0);
+    k0[r] = a; k1[r] = b;
+}
+
+// ---- 5. grouping ---------------------------------------------------------------------------------------------------
+__global__ void check_grouped(const uint32_t* __restrict__ qid, uint32_t n, uint32_t* __restrict__ unsorted) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > 0 && i < n && qid[i] < qid[i - 1]) *unsorted = 1u;
+}
+__global__ void iota_u32(uint32_t* __restrict__ v, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+__global__ void histogram_qid(const uint32_t* __restrict__ qid, uint32_t n, unsigned long long* __restrict__ count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&count[qid[i]], 1ull);
+}
+struct Cols { const int32_t* bs; const int32_t* aln; const uint32_t* tax; const uint32_t* arank; const double* pid; };
+struct ColsOut { int32_t* bs; int32_t* aln; uint32_t* tax; uint32_t* arank; double* pid; };
+__global__ void gather_cols(Cols in, ColsOut out, const uint32_t* __restrict__ perm, uint32_t n) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t i = perm ? perm[j] : j;
+    out.bs[j] = in.bs[i]; out.aln[j] = in.aln[i]; out.tax[j] = in.tax[i]; out.arank[j] = in.arank[i]; out.pid[j] = in.pid[i];
+}
+
+const char* fallback_text(uint32_t f) {
+    if (f & FB_EMPTY_LINE) return "an empty line";
+    if (f & FB_COLUMNS) return "a line with fewer than 13 columns (or an oversized field)";
+    if (f & FB_QUOTE) return "a quoted query / accession field";
+    if (f & FB_NUMBER) return "a numeric field outside the decimal fast path";
+    if (f & FB_RANGE) return "a number outside the engine's 32-bit columns";
+    if (f & FB_HASH_COLLISION) return "two strings with one 64-bit hash";
+    if (f & FB_TABLE_FULL) return "a dictionary table that filled up";
+    return "unknown";
+}
+
+uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1024; while (p < x) p <<= 1; return p; }
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int device, HitTable& ht, std::string* why) {
+    int rc = BLU_OK;
+    const bool trace = getenv("BLU_INGEST_TRACE") != nullptr;
+    double tp = now_s();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        (void)hipDeviceSynchronize();
+        const double t = now_s();
+        fprintf(stderr, "[ingest-gpu] %-26s %.3f s\n", what, t - tp);
+        tp = t;
+    };
+    auto fallback = [&](const char* reason) { if (why) *why = reason; return BLU_INGEST_FALLBACK; };
+    if (size == 0) return fallback("an empty file");
+    if (size >= (1ull << 44)) return fallback("a file of 16 TiB or more");
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return BLU_ERR_NO_DEVICE; }
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)size * 2.2 + (1ull << 30) > (double)free_b)
+            return fallback("a file too large for this device's free memory");
+    }
+
+    unsigned char* d_text = nullptr;
+    uint32_t *d_tile = nullptr, *d_tile_base = nullptr, *d_flags = nullptr, *d_counter = nullptr;
+    uint64_t* d_line = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    TaxidMap::E* d_taxmap = nullptr;
+    unsigned long long *d_qh = nullptr, *d_ah = nullptr, *d_qpos = nullptr, *d_apos = nullptr, *d_big = nullptr, *d_poslist = nullptr;
+    uint32_t *d_tax = nullptr, *d_qid = nullptr, *d_arank = nullptr, *d_list_row = nullptr, *d_list_slot = nullptr, *d_list_row2 = nullptr,
+             *d_list_slot2 = nullptr, *d_perm = nullptr, *d_perm2 = nullptr, *d_qid2 = nullptr, *d_ranks = nullptr;
+    double *d_pid = nullptr, *d_pid2 = nullptr;
+    int32_t *d_aln = nullptr, *d_bs = nullptr, *d_aln2 = nullptr, *d_bs2 = nullptr;
+    uint32_t *d_tax2 = nullptr, *d_arank2 = nullptr;
+    Slot *d_qtab = nullptr, *d_atab = nullptr;
+    unsigned long long* d_seg = nullptr;
+    uint32_t h_flags = 0, n_rows = 0, n_queries = 0, n_acc = 0;
+    uint64_t n_tiles = (size + TILE_BYTES - 1) / TILE_BYTES;
+    auto need_tmp = [&](size_t bytes) -> hipError_t {
+        if (bytes <= tmp_bytes) return hipSuccess;
+        if (d_tmp) (void)hipFree(d_tmp);
+        d_tmp = nullptr; tmp_bytes = 0;
+        hipError_t e = hipMalloc(&d_tmp, bytes);
+        if (e == hipSuccess) tmp_bytes = bytes;
+        return e;
+    };
+    auto grid = [](uint64_t n, uint32_t b = 256) { return dim3((unsigned)((n + b - 1) / b)); };
+
+    // ---- upload + line index
+    HIPCHK(hipMalloc((void**)&d_text, size + 64));
+    HIPCHK(hipMemset(d_text + (size & ~15ull), 0, 64 + (size & 15)));
+    HIPCHK(hipMemcpy(d_text, text, size, hipMemcpyHostToDevice));
+    lap("upload text");
+    HIPCHK(hipMalloc((void**)&d_tile, (n_tiles + 1) * 4));
+    HIPCHK(hipMalloc((void**)&d_tile_base, (n_tiles + 1) * 4));
+    HIPCHK(hipMalloc((void**)&d_flags, 64));
+    HIPCHK(hipMemset(d_flags, 0, 64));
+    d_counter = d_flags + 4;                                         // {flags, -, -, -, counter, -, big counters at +8}
+    d_big = reinterpret_cast<unsigned long long*>(d_flags + 8);      // [0] unmatched rows, [1] run heads
+    hipLaunchKernelGGL(count_newlines, grid(n_tiles, 1), dim3(TILE_THREADS), 0, 0, (const uint4*)d_text, (uint64_t)size, d_tile);
+    {
+        size_t b = 0;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_tile, d_tile_base, (int)(n_tiles + 1)));
+        HIPCHK(need_tmp(b));
+        HIPCHK(hipMemset(d_tile + n_tiles, 0, 4));
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, b, d_tile, d_tile_base, (int)(n_tiles + 1)));
+    }
+    {
+        uint32_t n_newlines = 0;
+        HIPCHK(hipMemcpy(&n_newlines, d_tile_base + n_tiles, 4, hipMemcpyDeviceToHost));
+        const bool open_tail = text[size - 1] != '\n';
+        const uint64_t rows64 = (uint64_t)n_newlines + (open_tail ? 1 : 0);
+        if (rows64 >= 0x7FFFFFF0ull) { rc = fallback("2^31 rows or more"); goto done; }
+        n_rows = (uint32_t)rows64;
+        if (n_rows == 0) { rc = fallback("no rows"); goto done; }
+        HIPCHK(hipMalloc((void**)&d_line, ((size_t)n_rows + 2) * 8));
+        HIPCHK(hipMemset(d_line, 0, 8));
+        hipLaunchKernelGGL(write_line_starts, grid(n_tiles, 1), dim3(TILE_THREADS), 0, 0, (const uint4*)d_text, (uint64_t)size, d_tile_base, d_line);
+        if (open_tail) { const uint64_t end = size + 1; HIPCHK(hipMemcpy(d_line + n_rows, &end, 8, hipMemcpyHostToDevice)); }
+    }
+    lap("line index");
+
+    // ---- parse
+    HIPCHK(hipMalloc((void**)&d_taxmap, row_of.tab.size() * sizeof(TaxidMap::E)));
+    HIPCHK(hipMemcpy(d_taxmap, row_of.tab.data(), row_of.tab.size() * sizeof(TaxidMap::E), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&d_qh, (size_t)n_rows * 8)); HIPCHK(hipMalloc((void**)&d_ah, (size_t)n_rows * 8));
+    HIPCHK(hipMalloc((void**)&d_qpos, (size_t)n_rows * 8)); HIPCHK(hipMalloc((void**)&d_apos, (size_t)n_rows * 8));
+    HIPCHK(hipMalloc((void**)&d_tax, (size_t)n_rows * 4)); HIPCHK(hipMalloc((void**)&d_pid, (size_t)n_rows * 8));
+    HIPCHK(hipMalloc((void**)&d_aln, (size_t)n_rows * 4)); HIPCHK(hipMalloc((void**)&d_bs, (size_t)n_rows * 4));
+    {
+        RowOut o{d_qh, d_ah, d_qpos, d_apos, d_tax, d_pid, d_aln, d_bs};
+        DevTaxidMap tm{d_taxmap, row_of.tab.size() - 1};
+        hipLaunchKernelGGL(parse_rows, grid(n_rows), dim3(256), 0, 0, d_text, d_line, n_rows, tm, o, d_flags, d_big);
+        HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
+        if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
+    }
+    lap("parse");
+
+    // ---- query dictionary: sized by the number of runs of equal hashes (an upper bound of the distinct count)
+    {
+        hipLaunchKernelGGL(count_run_heads, grid(n_rows), dim3(256), 0, 0, d_qh, n_rows, d_big + 1);
+        unsigned long long runs = 0;
+        HIPCHK(hipMemcpy(&runs, d_big + 1, 8, hipMemcpyDeviceToHost));
+        const uint64_t cap = pow2_at_least(runs * 2 + 16);
+        HIPCHK(hipMalloc((void**)&d_qtab, cap * sizeof(Slot)));
+        hipLaunchKernelGGL(dict_init, grid(cap), dim3(256), 0, 0, d_qtab, cap);   // empty slots, first_row = all ones for atomicMin
+        HIPCHK(hipMemset(d_counter, 0, 4));
+        hipLaunchKernelGGL(dict_insert, grid(n_rows), dim3(256), 0, 0, d_qh, n_rows, d_qtab, cap - 1, true, d_counter, d_flags);
+        HIPCHK(hipMemcpy(&n_queries, d_counter, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
+        if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
+        HIPCHK(hipMalloc((void**)&d_list_row, (size_t)n_queries * 4)); HIPCHK(hipMalloc((void**)&d_list_slot, (size_t)n_queries * 4));
+        HIPCHK(hipMalloc((void**)&d_list_row2, (size_t)n_queries * 4)); HIPCHK(hipMalloc((void**)&d_list_slot2, (size_t)n_queries * 4));
+        HIPCHK(hipMemset(d_counter, 0, 4));
+        hipLaunchKernelGGL(dict_finalize, grid(cap), dim3(256), 0, 0, d_qtab, cap, d_text, d_qpos, d_list_row, d_list_slot, d_counter);
+        size_t b = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, b, d_list_row, d_list_row2, d_list_slot, d_list_slot2, (int)n_queries));
+        HIPCHK(need_tmp(b));
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, b, d_list_row, d_list_row2, d_list_slot, d_list_slot2, (int)n_queries));
+        hipLaunchKernelGGL(dict_assign_ids, grid(n_queries), dim3(256), 0, 0, d_qtab, d_list_slot2, (const uint32_t*)nullptr, n_queries);
+        HIPCHK(hipMalloc((void**)&d_qid, (size_t)n_rows * 4));
+        hipLaunchKernelGGL(dict_lookup, grid(n_rows), dim3(256), 0, 0, d_qh, d_qpos, n_rows, d_qtab, cap - 1, d_text, d_qpos, d_qid, d_flags);
+        HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
+        if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
+        // query names: the text of each query's first row, in id order
+        HIPCHK(hipMalloc((void**)&d_poslist, (size_t)n_queries * 8));
+        hipLaunchKernelGGL(gather_pos, grid(n_queries), dim3(256), 0, 0, d_qpos, d_list_row2, n_queries, d_poslist);
+        std::vector<unsigned long long> qp(n_queries);
+        HIPCHK(hipMemcpy(qp.data(), d_poslist, (size_t)n_queries * 8, hipMemcpyDeviceToHost));
+        ht.query_names.resize(n_queries);
+        for (uint32_t q = 0; q < n_queries; ++q) ht.query_names[q].assign(text + (qp[q] & ((1ull << 44) - 1)), (size_t)(qp[q] >> 44));
+        (void)hipFree(d_poslist); d_poslist = nullptr;
+        (void)hipFree(d_list_row); (void)hipFree(d_list_slot); (void)hipFree(d_list_row2); (void)hipFree(d_list_slot2);
+        d_list_row = d_list_slot = d_list_row2 = d_list_slot2 = nullptr;
+        (void)hipFree(d_qtab); d_qtab = nullptr;
+        (void)hipFree(d_qh); d_qh = nullptr;
+        (void)hipFree(d_qpos); d_qpos = nullptr;
+    }
+    lap("query dictionary");
+
+    // ---- accession dictionary: distinct count unknown; the table grows until the load stays under one half
+    {
+        uint64_t cap = pow2_at_least(std::min<uint64_t>((uint64_t)n_rows * 2 + 16, 1ull << 22));
+        for (;;) {
+            HIPCHK(hipMalloc((void**)&d_atab, cap * sizeof(Slot)));
+            hipLaunchKernelGGL(dict_init, grid(cap), dim3(256), 0, 0, d_atab, cap);
+            HIPCHK(hipMemset(d_counter, 0, 4));
+            HIPCHK(hipMemset(d_flags, 0, 4));
+            hipLaunchKernelGGL(dict_insert, grid(n_rows), dim3(256), 0, 0, d_ah, n_rows, d_atab, cap - 1, false, d_counter, d_flags);
+            HIPCHK(hipMemcpy(&n_acc, d_counter, 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
+            if (!(h_flags & FB_TABLE_FULL) && (uint64_t)n_acc * 2 <= cap) break;
+            (void)hipFree(d_atab); d_atab = nullptr;
+            if (cap >= pow2_at_least((uint64_t)n_rows * 2 + 16)) { rc = fallback(fallback_text(FB_TABLE_FULL)); goto done; }
+            cap *= 4;
+        }
+        lap("  acc: insert");
+        HIPCHK(hipMemset(d_flags, 0, 4));
+        HIPCHK(hipMalloc((void**)&d_list_row, (size_t)n_acc * 4)); HIPCHK(hipMalloc((void**)&d_list_slot, (size_t)n_acc * 4));
+        HIPCHK(hipMemset(d_counter, 0, 4));
+        hipLaunchKernelGGL(dict_finalize, grid(cap), dim3(256), 0, 0, d_atab, cap, d_text, d_apos, d_list_row, d_list_slot, d_counter);
+        HIPCHK(hipMalloc((void**)&d_poslist, (size_t)n_acc * 8));
+        hipLaunchKernelGGL(gather_pos, grid(n_acc), dim3(256), 0, 0, d_apos, d_list_row, n_acc, d_poslist);
+        std::vector<unsigned long long> ap(n_acc);
+        HIPCHK(hipMemcpy(ap.data(), d_poslist, (size_t)n_acc * 8, hipMemcpyDeviceToHost));
+        lap("  acc: distinct to host");
+        // byte order of the distinct accessions (String::cmp), on the host: only the distinct strings are touched, and
+        // mostly not even those — the GPU hands over their first 16 bytes as two big-endian integers; the text is read
+        // only to order keys that agree on all 16
+        std::vector<unsigned long long> k0(n_acc), k1(n_acc);
+        {
+            unsigned long long *d_k0 = nullptr, *d_k1 = nullptr;
+            HIPCHK(hipMalloc((void**)&d_k0, (size_t)n_acc * 8 + 8));
+            hipError_t e2 = hipMalloc((void**)&d_k1, (size_t)n_acc * 8 + 8);
+            if (e2 == hipSuccess) {
+                hipLaunchKernelGGL(gather_key16, grid(n_acc), dim3(256), 0, 0, d_poslist, n_acc, d_text, d_k0, d_k1);
+                e2 = hipMemcpy(k0.data(), d_k0, (size_t)n_acc * 8, hipMemcpyDeviceToHost);
+                if (e2 == hipSuccess) e2 = hipMemcpy(k1.data(), d_k1, (size_t)n_acc * 8, hipMemcpyDeviceToHost);
+            }
+            (void)hipFree(d_k0);
+            if (d_k1) (void)hipFree(d_k1);
+            HIPCHK(e2);
+        }
+        std::vector<uint32_t> order(n_acc);
+        for (uint32_t k = 0; k < n_acc; ++k) order[k] = k;
+        auto view = [&](uint32_t k) { return std::string_view(text + (ap[k] & ((1ull << 44) - 1)), (size_t)(ap[k] >> 44)); };
+        auto less = [&](uint32_t a, uint32_t b) {
+            if (k0[a] != k0[b]) return k0[a] < k0[b];
+            if (k1[a] != k1[b]) return k1[a] < k1[b];
+            const size_t la = (size_t)(ap[a] >> 44), lb = (size_t)(ap[b] >> 44);
+            if (la <= 16 && lb <= 16) return la < lb;          // equal padded prefixes: the shorter string sorts first
+            return view(a) < view(b);
+        };
+        {
+            unsigned nt = std::thread::hardware_concurrency();
+            if (const char* env = getenv("BLU_INGEST_THREADS")) nt = (unsigned)atoi(env);
+            nt = std::max(1u, std::min(nt, 32u));
+            if (n_acc < 65536) nt = 1;
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; ++t)
+                pool.emplace_back([&, t]() { std::sort(order.begin() + (size_t)n_acc * t / nt, order.begin() + (size_t)n_acc * (t + 1) / nt, less); });
+            for (auto& th : pool) th.join();
+            for (unsigned w = 1; w < nt; w *= 2)
+                for (unsigned t = 0; t + w < nt; t += 2 * w)
+                    std::inplace_merge(order.begin() + (size_t)n_acc * t / nt, order.begin() + (size_t)n_acc * (t + w) / nt,
+                                       order.begin() + (size_t)n_acc * std::min(t + 2 * w, nt) / nt, less);
+        }
+        lap("  acc: host sort");
+        std::vector<uint32_t> rank_of(n_acc);
+        ht.accessions.resize(n_acc);
+        for (uint32_t r = 0; r < n_acc; ++r) { rank_of[order[r]] = r; ht.accessions[r].assign(view(order[r])); }
+        lap("  acc: strings");
+        HIPCHK(hipMalloc((void**)&d_ranks, (size_t)n_acc * 4));
+        HIPCHK(hipMemcpy(d_ranks, rank_of.data(), (size_t)n_acc * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(dict_assign_ids, grid(n_acc), dim3(256), 0, 0, d_atab, d_list_slot, (const uint32_t*)d_ranks, n_acc);
+        HIPCHK(hipMalloc((void**)&d_arank, (size_t)n_rows * 4));
+        hipLaunchKernelGGL(dict_lookup, grid(n_rows), dim3(256), 0, 0, d_ah, d_apos, n_rows, d_atab, cap - 1, d_text, d_apos, d_arank, d_flags);
+        HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
+        if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
+        (void)hipFree(d_atab); d_atab = nullptr;
+        (void)hipFree(d_ah); d_ah = nullptr;
+        (void)hipFree(d_apos); d_apos = nullptr;
+        (void)hipFree(d_text); d_text = nullptr;
+    }
+    lap("accession dictionary");
+
+    // ---- grouping: queries in first-appearance order, file order inside a query (mod.rs:192-208)
+    {
+        HIPCHK(hipMemset(d_counter, 0, 4));
+        hipLaunchKernelGGL(check_grouped, grid(n_rows), dim3(256), 0, 0, d_qid, n_rows, d_counter);
+        uint32_t unsorted = 0;
+        HIPCHK(hipMemcpy(&unsorted, d_counter, 4, hipMemcpyDeviceToHost));
+        if (unsorted) {
+            HIPCHK(hipMalloc((void**)&d_perm, (size_t)n_rows * 4)); HIPCHK(hipMalloc((void**)&d_perm2, (size_t)n_rows * 4));
+            HIPCHK(hipMalloc((void**)&d_qid2, (size_t)n_rows * 4));
+            hipLaunchKernelGGL(iota_u32, grid(n_rows), dim3(256), 0, 0, d_perm, n_rows);
+            int bits = 1;
+            while ((1ull << bits) < n_queries) ++bits;
+            size_t b = 0;
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, b, d_qid, d_qid2, d_perm, d_perm2, (int)n_rows, 0, bits));
+            HIPCHK(need_tmp(b));
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, b, d_qid, d_qid2, d_perm, d_perm2, (int)n_rows, 0, bits));   // stable
+        }
+        HIPCHK(hipMalloc((void**)&d_seg, ((size_t)n_queries + 1) * 8 * 2));
+        HIPCHK(hipMemset(d_seg, 0, ((size_t)n_queries + 1) * 8 * 2));
+        hipLaunchKernelGGL(histogram_qid, grid(n_rows), dim3(256), 0, 0, d_qid, n_rows, d_seg);
+        size_t b = 0;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_seg, d_seg + n_queries + 1, (int)(n_queries + 1)));
+        HIPCHK(need_tmp(b));
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, b, d_seg, d_seg + n_queries + 1, (int)(n_queries + 1)));
+        HIPCHK(hipMalloc((void**)&d_bs2, (size_t)n_rows * 4)); HIPCHK(hipMalloc((void**)&d_aln2, (size_t)n_rows * 4));
+        HIPCHK(hipMalloc((void**)&d_tax2, (size_t)n_rows * 4)); HIPCHK(hipMalloc((void**)&d_arank2, (size_t)n_rows * 4));
+        HIPCHK(hipMalloc((void**)&d_pid2, (size_t)n_rows * 8));
+        Cols in{d_bs, d_aln, d_tax, d_arank, d_pid};
+        ColsOut out{d_bs2, d_aln2, d_tax2, d_arank2, d_pid2};
+        hipLaunchKernelGGL(gather_cols, grid(n_rows), dim3(256), 0, 0, in, out, (const uint32_t*)(unsorted ? d_perm2 : nullptr), n_rows);
+    }
+    lap("grouping");
+
+    // ---- results to the host
+    {
+        // one host thread per column: the first touch of the fresh host pages costs more than the copy itself
+        hipError_t errs[6] = {hipSuccess, hipSuccess, hipSuccess, hipSuccess, hipSuccess, hipSuccess};
+        auto fetch = [&](int k, auto& vec, const void* src, size_t n) {
+            return std::thread([&errs, &vec, k, src, n, device]() {
+                (void)hipSetDevice(device);
+                vec.resize(n);
+                errs[k] = hipMemcpy(vec.data(), src, n * sizeof(vec[0]), hipMemcpyDeviceToHost);
+            });
+        };
+        std::thread th[6] = {fetch(0, ht.seg_off, d_seg + n_queries + 1, (size_t)n_queries + 1), fetch(1, ht.bitscore, d_bs2, n_rows),
+                             fetch(2, ht.align_len, d_aln2, n_rows), fetch(3, ht.tax_desc_row, d_tax2, n_rows),
+                             fetch(4, ht.acc_rank, d_arank2, n_rows), fetch(5, ht.pident, d_pid2, n_rows)};
+        for (auto& t : th) t.join();
+        for (hipError_t e : errs) HIPCHK(e);
+        unsigned long long unmatched = 0;
+        HIPCHK(hipMemcpy(&unmatched, d_big, 8, hipMemcpyDeviceToHost));
+        ht.unmatched = unmatched;
+    }
+    lap("download columns");
+
+done:
+    for (void* p : {(void*)d_text, (void*)d_tile, (void*)d_tile_base, (void*)d_flags, (void*)d_line, d_tmp, (void*)d_taxmap, (void*)d_qh, (void*)d_ah,
+                    (void*)d_qpos, (void*)d_apos, (void*)d_poslist, (void*)d_tax, (void*)d_qid, (void*)d_arank, (void*)d_list_row, (void*)d_list_slot,
+                    (void*)d_list_row2, (void*)d_list_slot2, (void*)d_perm, (void*)d_perm2, (void*)d_qid2, (void*)d_ranks, (void*)d_pid, (void*)d_pid2,
+                    (void*)d_aln, (void*)d_bs, (void*)d_aln2, (void*)d_bs2, (void*)d_tax2, (void*)d_arank2, (void*)d_qtab, (void*)d_atab, (void*)d_seg})
+        if (p) (void)hipFree(p);
+    if (rc != BLU_OK) {
+        ht = HitTable();
+    }
+    return rc;
+}
+
+}  // namespace blu

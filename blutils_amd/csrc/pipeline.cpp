@@ -32,6 +32,7 @@
 
 #include "blu_internal.h"
 #include "blu_pipeline.h"
+#include "ingest.h"
 
 using namespace blu;
 
@@ -140,41 +141,6 @@ struct Json {
 // ---------------------------------------------------------------------------------------------------------
 // taxonomy side
 // ---------------------------------------------------------------------------------------------------------
-// taxid -> row of the taxonomy table; open addressing, 16-byte entries (one cache line touched per lookup: the join
-// runs once per hit row).  First insertion wins for a duplicated taxid.
-struct TaxidMap {
-    struct E { int64_t key; uint32_t val, used; };
-    std::vector<E> tab = std::vector<E>(1024, E{0, 0, 0});
-    size_t n = 0;
-    static uint64_t mixk(int64_t k) { uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull; return x ^ (x >> 32); }
-    void rehash(size_t cap) {
-        std::vector<E> old(cap, E{0, 0, 0});
-        old.swap(tab);
-        for (const E& e : old) if (e.used) put(e.key, e.val);
-    }
-    void put(int64_t k, uint32_t v) {
-        const size_t m = tab.size() - 1;
-        size_t i = mixk(k) & m;
-        while (tab[i].used) { if (tab[i].key == k) return; i = (i + 1) & m; }
-        tab[i] = E{k, v, 1};
-    }
-    void reserve(size_t want) { size_t cap = tab.size(); while (cap < want * 2) cap *= 2; if (cap != tab.size()) rehash(cap); }
-    void emplace(int64_t k, uint32_t v) {
-        if ((n + 1) * 2 > tab.size()) rehash(tab.size() * 2);
-        const size_t m = tab.size() - 1;
-        size_t i = mixk(k) & m;
-        while (tab[i].used) { if (tab[i].key == k) return; i = (i + 1) & m; }
-        tab[i] = E{k, v, 1};
-        ++n;
-    }
-    uint32_t find_or(int64_t k, uint32_t missing) const {
-        const size_t m = tab.size() - 1;
-        size_t i = mixk(k) & m;
-        while (tab[i].used) { if (tab[i].key == k) return tab[i].val; i = (i + 1) & m; }
-        return missing;
-    }
-};
-
 struct Db {
     std::vector<int64_t> taxid;
     std::vector<uint64_t> lin_off{0};
@@ -387,16 +353,6 @@ int load_db(const char* path, bool use_taxid, Db& db) {
 // ---------------------------------------------------------------------------------------------------------
 // hit table side
 // ---------------------------------------------------------------------------------------------------------
-struct HitTable {
-    std::vector<std::string> query_names;        // first-appearance order
-    std::vector<uint64_t> seg_off;
-    std::vector<int32_t> bitscore, align_len;
-    std::vector<uint32_t> tax_desc_row, acc_rank;   // acc_rank: rank of the accession in byte order = index into `accessions`
-    std::vector<double> pident;
-    std::vector<std::string> accessions;         // sorted (String::cmp)
-    uint64_t unmatched = 0;
-};
-
 std::string strip_quotes(std::string_view v) {   // mod.rs:169-172 `.replace("\"", "")`
     std::string s;
     s.reserve(v.size());
@@ -601,9 +557,25 @@ void parallel_for(unsigned n, unsigned nthreads, F&& f) {
 // Afterwards only the DISTINCT strings are merged — queries in file order (first appearance decides a query's
 // position, mod.rs:192-208), accessions by a tree of sorted-list merges (their id is their rank in byte order) —
 // and the workers scatter their rows into the grouped table.  The result does not depend on the thread count.
-int load_hits(const char* path, const Db& db, HitTable& ht) {
+thread_local int g_last_ingest_path = 0;   // 0 = CPU parser, 1 = GPU parser (blu_last_ingest_path)
+
+int load_hits(const char* path, const Db& db, HitTable& ht, int device = -1) {
+    g_last_ingest_path = 0;
     MappedFile f;
     if (!f.open(path)) { set_error("Unexpected error occurred on load table: %s", path); return BLU_ERR_IO; }
+    // GPU parser first (ingest_gpu.hip) when a device is given: same columns bit for bit; files it does not handle
+    // (quotes, empty lines, unusual numbers), small files and BLU_INGEST=cpu take the CPU path below
+    {
+        const char* mode = getenv("BLU_INGEST");
+        const bool want_gpu = device >= 0 && !(mode && strcmp(mode, "cpu") == 0) && (f.size >= (1u << 20) || (mode && strcmp(mode, "gpu") == 0));
+        if (want_gpu) {
+            std::string why;
+            const int rc = load_hits_gpu(f.data, f.size, db.row_of, device, ht, &why);
+            if (rc == BLU_OK) { g_last_ingest_path = 1; return BLU_OK; }
+            if (rc != BLU_INGEST_FALLBACK) return rc;
+            if (getenv("BLU_INGEST_TRACE")) fprintf(stderr, "[ingest] GPU parser declined (%s): CPU path\n", why.c_str());
+        }
+    }
     unsigned nthreads = std::thread::hardware_concurrency();
     if (const char* env = getenv("BLU_INGEST_THREADS")) nthreads = (unsigned)atoi(env);
     if (nthreads < 1) nthreads = 1;
@@ -984,7 +956,7 @@ int blu_build_consensus_identities_cfg(const char* blast_output_file, const char
     st.t_load_db_s = now_s() - t0;
     t0 = now_s();
     HitTable ht;
-    rc = load_hits(blast_output_file, db, ht);                         // mod.rs:54, 72-82
+    rc = load_hits(blast_output_file, db, ht, params->device);         // mod.rs:54, 72-82
     if (rc != BLU_OK) return rc;
     st.t_load_hits_s = now_s() - t0;
     st.n_hits = ht.bitscore.size(); st.n_queries = ht.query_names.size(); st.n_taxids = db.taxid.size(); st.n_unmatched_rows = ht.unmatched;
@@ -1138,6 +1110,11 @@ void blu_free_text(char* text) { free(text); }
 
 int blu_ingest_only(const char* blast_output_file, const char* taxonomies_file, int use_taxid, blu_pipeline_stats* stats,
                     uint64_t* checksum) {
+    return blu_ingest_only_on(blast_output_file, taxonomies_file, use_taxid, -1, stats, checksum);
+}
+
+int blu_ingest_only_on(const char* blast_output_file, const char* taxonomies_file, int use_taxid, int device,
+                       blu_pipeline_stats* stats, uint64_t* checksum) {
     if (!blast_output_file || !taxonomies_file) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
     blu_pipeline_stats st{};
     double t0 = now_s();
@@ -1147,7 +1124,7 @@ int blu_ingest_only(const char* blast_output_file, const char* taxonomies_file, 
     st.t_load_db_s = now_s() - t0;
     t0 = now_s();
     HitTable ht;
-    rc = load_hits(blast_output_file, db, ht);
+    rc = load_hits(blast_output_file, db, ht, device);
     if (rc != BLU_OK) return rc;
     st.t_load_hits_s = now_s() - t0;
     st.n_hits = ht.bitscore.size(); st.n_queries = ht.query_names.size(); st.n_taxids = db.taxid.size(); st.n_unmatched_rows = ht.unmatched;
@@ -1159,12 +1136,15 @@ int blu_ingest_only(const char* blast_output_file, const char* taxonomies_file, 
         mix(ht.align_len.data(), ht.align_len.size() * 4); mix(ht.tax_desc_row.data(), ht.tax_desc_row.size() * 4);
         mix(ht.acc_rank.data(), ht.acc_rank.size() * 4); mix(ht.pident.data(), ht.pident.size() * 8);
         for (auto& q : ht.query_names) mix(q.data(), q.size() + 1);
+        for (auto& a : ht.accessions) mix(a.data(), a.size() + 1);
         *checksum = h;
     }
     return BLU_OK;
 }
 
 // domain/dtos/taxon.rs:28-66: YAML (flat `key: value` lines) or JSON object with the eight fields
+int blu_last_ingest_path(void) { return g_last_ingest_path; }
+
 int blu_db_cache_build(const char* taxonomies_file, int use_taxid, const char* cache_file) {
     if (!taxonomies_file || !cache_file) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
     Db db;

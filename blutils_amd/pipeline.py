@@ -39,16 +39,22 @@ def _bind():
     return L
 
 
-def ingest_only(blast_output: str, taxonomies_file: str, use_taxid: bool = False):
-    """Text ingest alone (no GPU): returns (stats, checksum of the SoA columns)."""
+def ingest_only(blast_output: str, taxonomies_file: str, use_taxid: bool = False, device: int = -1):
+    """Text ingest alone: returns (stats, checksum of the SoA columns).  device < 0: CPU ingest (no GPU needed);
+    device >= 0: the GPU parser where it applies (same columns, same checksum)."""
     L = _bind()
-    L.blu_ingest_only.restype = C.c_int
-    L.blu_ingest_only.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(PipelineStats), C.POINTER(C.c_uint64)]
+    L.blu_ingest_only_on.restype = C.c_int
+    L.blu_ingest_only_on.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(PipelineStats), C.POINTER(C.c_uint64)]
     st, ck = PipelineStats(), C.c_uint64()
-    rc = L.blu_ingest_only(blast_output.encode(), taxonomies_file.encode(), 1 if use_taxid else 0, C.byref(st), C.byref(ck))
+    rc = L.blu_ingest_only_on(blast_output.encode(), taxonomies_file.encode(), 1 if use_taxid else 0, device, C.byref(st), C.byref(ck))
     if rc != N.BLU_OK:
         raise N.BluError(rc, "blu_ingest_only")
     return {f: getattr(st, f) for f, _ in PipelineStats._fields_}, ck.value
+
+
+def last_ingest_path() -> str:
+    """'gpu' or 'cpu': the parser the last ingest of this thread used."""
+    return "gpu" if N.lib().blu_last_ingest_path() == 1 else "cpu"
 
 
 def build_db_cache(taxonomies_file: str, cache_file: str, use_taxid: bool = False) -> None:

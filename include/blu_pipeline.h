@@ -78,6 +78,14 @@ void blu_free_text(char* text);
  * timing the ingest (rows/s) apart from the engine. */
 int blu_ingest_only(const char* blast_output_file, const char* taxonomies_file, int use_taxid, blu_pipeline_stats* stats,
                     uint64_t* checksum);
+/* The same on HIP device `device` (>= 0): the table is parsed by the GPU ingest (csrc/ingest_gpu.hip) when it is in the
+ * plain form BLAST writes, by the CPU otherwise; the columns — and the checksum — are identical either way.
+ * BLU_INGEST=cpu|gpu in the environment forces one of the two (gpu also for files under 1 MiB). */
+int blu_ingest_only_on(const char* blast_output_file, const char* taxonomies_file, int use_taxid, int device,
+                       blu_pipeline_stats* stats, uint64_t* checksum);
+
+/* Which parser the calling thread's last ingest used: 0 = CPU, 1 = GPU. */
+int blu_last_ingest_path(void);
 
 /* Binary cache of the taxonomies file.  The reference re-parses the `*.blutils.json` on every run
  * (mod.rs:246-327, taxonomies_map.rs:6-32) and keeps only {taxid, numericLineage | textLineage}; this writes exactly

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--threads", default="1,4,16")
     ap.add_argument("--accessions", default="clustered", choices=["clustered", "uniform"])
     ap.add_argument("--dir", default="/tmp/blu_ingest_bench")
+    ap.add_argument("--gpu", action="store_true", help="also time the GPU parser (device 0) and check it gives the same columns")
     ap.add_argument("--pipeline", action="store_true", help="also run the whole use-case on the GPU (JSONL out) and print its stage times")
     args = ap.parse_args()
     from blutils_amd import pipeline
@@ -74,6 +75,18 @@ def main():
         phases = " | ".join(l.split("]")[1].strip() for l in p.stderr.splitlines() if l.startswith("[ingest]"))
         print(f"threads {th:2d}: {st['t_load_hits_s']:.3f} s = {rows / st['t_load_hits_s'] / 1e6:.2f} M rows/s = "
               f"{size / st['t_load_hits_s'] / 1e9:.2f} GB/s   (db load {st['t_load_db_s']:.3f} s)   [{phases}]")
+    if args.gpu:
+        code_g = ("import sys, json; sys.path.insert(0, %r); from blutils_amd import pipeline; "
+                  "pipeline.ingest_only(%r, %r, False, 0); "     # first call: HIP start-up
+                  "print(json.dumps(pipeline.ingest_only(%r, %r, False, 0) + (pipeline.last_ingest_path(),)))" % (ROOT, bt, cache, bt, cache))
+        env = dict(os.environ, BLU_INGEST_TRACE="1")
+        p = subprocess.run([sys.executable, "-c", code_g], env=env, capture_output=True, text=True, check=True)
+        st, ck, path = json.loads(p.stdout.strip().splitlines()[-1])
+        assert ck == ref and path == "gpu", (ck, ref, path)
+        lines = [l.split("]")[1].strip() for l in p.stderr.splitlines() if l.startswith("[ingest-gpu]")]
+        phases = " | ".join(lines[len(lines) // 2:])
+        print(f"GPU parser: {st['t_load_hits_s']:.3f} s = {rows / st['t_load_hits_s'] / 1e6:.1f} M rows/s = "
+              f"{size / st['t_load_hits_s'] / 1e9:.2f} GB/s of text, same columns   [{phases}]")
     if args.pipeline:
         t0 = time.time()
         text, st = pipeline.build_consensus_identities(bt, cache, "bacteria", "relaxed", out_format="jsonl", lenient=True, parse=False)
