@@ -4,8 +4,11 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
+
+#include "blu_consensus.h"
 
 namespace blu {
 
@@ -44,6 +47,21 @@ struct TaxidMap {
     }
 };
 
+// Device copies of the grouped columns, left behind by the GPU ingest so that the engine reads them in place (no second
+// trip over PCIe).  Owned by the HitTable; freed with it.
+struct DeviceHits {
+    int device = -1;
+    uint64_t n_hits = 0, n_queries = 0;
+    int32_t* bitscore = nullptr;
+    int32_t* align_len = nullptr;
+    uint32_t* tax_desc_row = nullptr;   // rewritten in place to engine row ids by device_run_consensus
+    uint32_t* acc_rank = nullptr;
+    double* pident = nullptr;
+    unsigned long long* seg_off = nullptr;   // [n_queries + 1]
+    void* seg_block = nullptr;               // allocation seg_off lives in
+    ~DeviceHits();
+};
+
 // What the ingest hands to the engine and the renderer (a2 + a4 + a5 of SURVEY 8a).
 struct HitTable {
     std::vector<std::string> query_names;        // first-appearance order
@@ -53,6 +71,7 @@ struct HitTable {
     std::vector<double> pident;
     std::vector<std::string> accessions;         // sorted (String::cmp)
     uint64_t unmatched = 0;
+    std::unique_ptr<DeviceHits> dev;             // set by the GPU ingest
 };
 
 
@@ -62,6 +81,11 @@ struct HitTable {
 // files in the plain BLAST form (no quotes, no empty lines, numbers of <= 15 significant digits); anything else returns
 // BLU_INGEST_FALLBACK with the reason in *why and the caller parses on the CPU.
 int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int device, HitTable& ht, std::string* why);
+
+// The engine on the columns the GPU ingest left on the device: taxonomy rows -> engine row ids (fwd = blu_taxonomy_row_map's
+// forward table), perc_identity as milli-percent when every value is exactly k/1000 (checked on the device), one
+// blu_consensus_run with device pointers, records copied to `out` (host).  Frees the device columns.
+int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_t* fwd, uint64_t n_tax, int strategy, blu_result* out);
 
 }  // namespace blu
 #endif

@@ -622,6 +622,12 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         unsigned long long unmatched = 0;
         HIPCHK(hipMemcpy(&unmatched, d_big, 8, hipMemcpyDeviceToHost));
         ht.unmatched = unmatched;
+        // the grouped columns stay on the device for the engine
+        ht.dev.reset(new DeviceHits());
+        ht.dev->device = device; ht.dev->n_hits = n_rows; ht.dev->n_queries = n_queries;
+        ht.dev->bitscore = d_bs2; ht.dev->align_len = d_aln2; ht.dev->tax_desc_row = d_tax2; ht.dev->acc_rank = d_arank2; ht.dev->pident = d_pid2;
+        ht.dev->seg_off = d_seg + n_queries + 1; ht.dev->seg_block = d_seg;
+        d_bs2 = d_aln2 = nullptr; d_tax2 = d_arank2 = nullptr; d_pid2 = nullptr; d_seg = nullptr;
     }
     lap("download columns");
 
@@ -634,6 +640,74 @@ done:
     if (rc != BLU_OK) {
         ht = HitTable();
     }
+    return rc;
+}
+
+
+// ---- engine on the resident columns ---------------------------------------------------------------------------
+namespace {
+__global__ void to_engine_rows(uint32_t* __restrict__ rows, uint64_t n, const uint32_t* __restrict__ fwd, uint64_t n_tax) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = rows[i];
+    rows[i] = (r == BLU_UNMATCHED_TAXID || r >= n_tax) ? BLU_UNMATCHED_TAXID : fwd[r];
+}
+// k = round(p * 1000) is used only if fl(k / 1000.0) == p bit for bit for every row (the 20 B/hit layout is lossless then)
+__global__ void to_milli(const double* __restrict__ pid, uint64_t n, uint32_t* __restrict__ milli, uint32_t* __restrict__ inexact) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double p = pid[i];
+    bool ok = p >= 0.0 && p < 4.0e6;
+    uint32_t k = 0;
+    if (ok) {
+        k = (uint32_t)(p * 1000.0 + 0.5);
+        const double back = (double)k / 1000.0;
+        ok = __double_as_longlong(back) == __double_as_longlong(p);
+    }
+    milli[i] = k;
+    if (!ok) *inexact = 1u;
+}
+}  // namespace
+
+DeviceHits::~DeviceHits() {
+    if (device < 0) return;
+    (void)hipSetDevice(device);
+    for (void* p : {(void*)bitscore, (void*)align_len, (void*)tax_desc_row, (void*)acc_rank, (void*)pident, seg_block})
+        if (p) (void)hipFree(p);
+}
+
+int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_t* fwd, uint64_t n_tax, int strategy, blu_result* out) {
+    int rc = BLU_OK;
+    uint32_t *d_fwd = nullptr, *d_milli = nullptr, *d_flag = nullptr;
+    blu_result* d_out = nullptr;
+    uint32_t inexact = 0;
+    const uint64_t n = dev.n_hits;
+    auto grid = [](uint64_t m) { return dim3((unsigned)((m + 255) / 256)); };
+    if (hipSetDevice(dev.device) != hipSuccess) { set_error("hipSetDevice(%d) failed", dev.device); return BLU_ERR_NO_DEVICE; }
+    HIPCHK(hipMalloc((void**)&d_fwd, std::max<uint64_t>(n_tax, 1) * 4));
+    HIPCHK(hipMemcpy(d_fwd, fwd, n_tax * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&d_milli, std::max<uint64_t>(n, 1) * 4));
+    HIPCHK(hipMalloc((void**)&d_flag, 4));
+    HIPCHK(hipMemset(d_flag, 0, 4));
+    HIPCHK(hipMalloc((void**)&d_out, std::max<uint64_t>(dev.n_queries, 1) * sizeof(blu_result)));
+    if (n) {
+        hipLaunchKernelGGL(to_engine_rows, grid(n), dim3(256), 0, 0, dev.tax_desc_row, n, d_fwd, n_tax);
+        hipLaunchKernelGGL(to_milli, grid(n), dim3(256), 0, 0, dev.pident, n, d_milli, d_flag);
+    }
+    HIPCHK(hipMemcpy(&inexact, d_flag, 4, hipMemcpyDeviceToHost));
+    {
+        blu_hits h{};
+        h.bitscore = dev.bitscore; h.tax_row = dev.tax_desc_row; h.align_len = dev.align_len; h.acc_rank = dev.acc_rank;
+        h.seg_off = (const uint64_t*)dev.seg_off;
+        if (inexact) h.pident = dev.pident; else h.pident_milli = d_milli;
+        h.n_hits = n; h.n_queries = dev.n_queries; h.on_device = 1;
+        blu_run_params rp{strategy, 0, nullptr};
+        rc = blu_consensus_run(tax, &h, &rp, d_out);
+        if (rc != BLU_OK) goto done;
+    }
+    HIPCHK(hipMemcpy(out, d_out, dev.n_queries * sizeof(blu_result), hipMemcpyDeviceToHost));   // waits for the null stream
+done:
+    for (void* p : {(void*)d_fwd, (void*)d_milli, (void*)d_flag, (void*)d_out}) if (p) (void)hipFree(p);
     return rc;
 }
 

@@ -978,31 +978,38 @@ int blu_build_consensus_identities_cfg(const char* blast_output_file, const char
     if (rc != BLU_OK) return rc;
     std::vector<uint32_t> fwd(std::max<size_t>(db.taxid.size(), 1));
     blu_taxonomy_row_map(tax, fwd.data(), nullptr);
-    std::vector<uint32_t> eng_rows(ht.tax_desc_row.size());
-    for (size_t i = 0; i < eng_rows.size(); ++i)
-        eng_rows[i] = ht.tax_desc_row[i] == BLU_UNMATCHED_TAXID ? BLU_UNMATCHED_TAXID : fwd[ht.tax_desc_row[i]];
     std::vector<blu_result> recs(ht.query_names.size());
-    if (!recs.empty()) {
-        blu_hits h{};
-        h.bitscore = ht.bitscore.data(); h.tax_row = eng_rows.data();
-        // 20 B/hit layout when every perc_identity is exactly k/1000 (BLAST prints <= 3 decimals): verified per value,
-        // so the engine's fl(k / 1000.0) is bit-identical to the parsed f64; otherwise the f64 column goes over.
-        std::vector<uint32_t> milli(ht.pident.size());
-        bool exact = true;
-        for (size_t i = 0; i < milli.size() && exact; ++i) {
-            const double p = ht.pident[i];
-            if (!(p >= 0.0 && p < 4.0e6)) { exact = false; break; }
-            const uint32_t k = (uint32_t)(p * 1000.0 + 0.5);
-            const double back = (double)k / 1000.0;
-            exact = memcmp(&back, &p, 8) == 0;
-            milli[i] = k;
-        }
-        if (exact) h.pident_milli = milli.data(); else h.pident = ht.pident.data();
-        h.align_len = ht.align_len.data(); h.acc_rank = ht.acc_rank.data(); h.seg_off = ht.seg_off.data();
-        h.n_hits = ht.bitscore.size(); h.n_queries = ht.query_names.size(); h.on_device = 0;
-        blu_run_params rp{params->strategy, 0, nullptr};
-        rc = blu_consensus_run(tax, &h, &rp, recs.data());             // mod.rs:104-128
+    if (ht.dev && !recs.empty()) {
+        // the GPU ingest left the grouped columns on the device: the engine reads them in place
+        rc = device_run_consensus(tax, *ht.dev, fwd.data(), db.taxid.size(), params->strategy, recs.data());   // mod.rs:104-128
+        ht.dev.reset();
         if (rc != BLU_OK) { blu_taxonomy_destroy(tax); return rc; }
+    } else {
+        std::vector<uint32_t> eng_rows(ht.tax_desc_row.size());
+        for (size_t i = 0; i < eng_rows.size(); ++i)
+            eng_rows[i] = ht.tax_desc_row[i] == BLU_UNMATCHED_TAXID ? BLU_UNMATCHED_TAXID : fwd[ht.tax_desc_row[i]];
+        if (!recs.empty()) {
+            blu_hits h{};
+            h.bitscore = ht.bitscore.data(); h.tax_row = eng_rows.data();
+            // 20 B/hit layout when every perc_identity is exactly k/1000 (BLAST prints <= 3 decimals): verified per value,
+            // so the engine's fl(k / 1000.0) is bit-identical to the parsed f64; otherwise the f64 column goes over.
+            std::vector<uint32_t> milli(ht.pident.size());
+            bool exact = true;
+            for (size_t i = 0; i < milli.size() && exact; ++i) {
+                const double p = ht.pident[i];
+                if (!(p >= 0.0 && p < 4.0e6)) { exact = false; break; }
+                const uint32_t k = (uint32_t)(p * 1000.0 + 0.5);
+                const double back = (double)k / 1000.0;
+                exact = memcmp(&back, &p, 8) == 0;
+                milli[i] = k;
+            }
+            if (exact) h.pident_milli = milli.data(); else h.pident = ht.pident.data();
+            h.align_len = ht.align_len.data(); h.acc_rank = ht.acc_rank.data(); h.seg_off = ht.seg_off.data();
+            h.n_hits = ht.bitscore.size(); h.n_queries = ht.query_names.size(); h.on_device = 0;
+            blu_run_params rp{params->strategy, 0, nullptr};
+            rc = blu_consensus_run(tax, &h, &rp, recs.data());             // mod.rs:104-128
+            if (rc != BLU_OK) { blu_taxonomy_destroy(tax); return rc; }
+        }
     }
     st.t_engine_s = now_s() - t0;
 
