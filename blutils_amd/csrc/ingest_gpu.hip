@@ -208,11 +208,13 @@ __global__ __launch_bounds__(256) void parse_rows(const unsigned char* __restric
 }
 
 // ---- 3. dictionaries ---------------------------------------------------------------------------------------------
-__global__ void count_run_heads(const unsigned long long* __restrict__ h, uint32_t n, unsigned long long* __restrict__ count) {
+__global__ __launch_bounds__(1024) void count_run_heads(const unsigned long long* __restrict__ h, uint32_t n, unsigned long long* __restrict__ count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool head = i < n && (i == 0 || h[i] != h[i - 1]);
-    const unsigned long long m = __ballot(head);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+    const uint32_t head = i < n && (i == 0 || h[i] != h[i - 1]);
+    typedef hipcub::BlockReduce<uint32_t, 1024> BR;
+    __shared__ typename BR::TempStorage tmp;
+    const uint32_t total = BR(tmp).Sum(head);
+    if (threadIdx.x == 0 && total) atomicAdd(count, (unsigned long long)total);   // one atomic per 1024 rows
 }
 
 __global__ void dict_init(Slot* __restrict__ tab, uint64_t n_slots) {
@@ -444,7 +446,7 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
 
     // ---- query dictionary: sized by the number of runs of equal hashes (an upper bound of the distinct count)
     {
-        hipLaunchKernelGGL(count_run_heads, grid(n_rows), dim3(256), 0, 0, d_qh, n_rows, d_big + 1);
+        hipLaunchKernelGGL(count_run_heads, grid(n_rows, 1024), dim3(1024), 0, 0, d_qh, n_rows, d_big + 1);
         unsigned long long runs = 0;
         HIPCHK(hipMemcpy(&runs, d_big + 1, 8, hipMemcpyDeviceToHost));
         const uint64_t cap = pow2_at_least(runs * 2 + 16);
