@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("BLU_CONSENSUS_LIB") or os.path.join(_HERE, "lib", "li
 
 # every symbol include/blu_consensus.h declares
 EXPORTS = (
-    "blu_abi_version", "blu_last_error", "blu_taxonomy_create", "blu_taxonomy_destroy", "blu_taxonomy_n_tax",
+    "blu_abi_version", "blu_last_error", "blu_consensus_run_multi", "blu_shard_ranges", "blu_taxonomy_create", "blu_taxonomy_destroy", "blu_taxonomy_n_tax",
     "blu_taxonomy_n_shapes", "blu_taxonomy_n_rank_codes", "blu_taxonomy_max_depth", "blu_taxonomy_device_bytes",
     "blu_taxonomy_rank_name", "blu_taxonomy_row_cutoffs", "blu_taxonomy_lookup", "blu_taxonomy_row_map", "blu_consensus_run",
     "blu_consensus_last_launch",

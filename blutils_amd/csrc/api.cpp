@@ -7,6 +7,11 @@
 #include <cstdio>
 #include <cstring>
 
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <vector>
+
 #include "blu_internal.h"
 
 using namespace blu;
@@ -99,6 +104,70 @@ done:
     if (d_seg) (void)hipFree(d_seg);
     if (d_out) (void)hipFree(d_out);
     return rc;
+}
+
+int blu_shard_ranges(const uint64_t* seg_off, uint64_t n_queries, uint32_t n_shards, uint64_t* bounds) {
+    if (!seg_off || !bounds || n_shards == 0) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    const uint64_t base = seg_off[0];
+    const uint64_t total = seg_off[n_queries] >= base ? seg_off[n_queries] - base : 0;
+    bounds[0] = 0;
+    for (uint32_t p = 1; p < n_shards; ++p) {
+        const uint64_t target = base + (uint64_t)((unsigned __int128)total * p / n_shards);
+        const uint64_t* it = std::lower_bound(seg_off, seg_off + n_queries + 1, target);
+        uint64_t q = (uint64_t)(it - seg_off);
+        if (q > n_queries) q = n_queries;
+        // the boundary nearest to the target, never moving backwards
+        if (q > 0 && target - seg_off[q - 1] <= seg_off[q] - target) --q;
+        bounds[p] = std::max(q, bounds[p - 1]);
+    }
+    bounds[n_shards] = n_queries;
+    return BLU_OK;
+}
+
+int blu_consensus_run_multi(const blu_taxonomy* const* taxes, uint32_t n, const blu_hits* hits, const blu_run_params* params,
+                            blu_result* out) {
+    if (!taxes || n == 0 || !hits || !params) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    if (hits->on_device) { set_error("blu_consensus_run_multi takes host pointers"); return BLU_ERR_INVALID_ARG; }
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!taxes[i]) { set_error("null taxonomy handle"); return BLU_ERR_INVALID_ARG; }
+        for (uint32_t j = 0; j < i; ++j)
+            if (taxes[j] == taxes[i]) { set_error("a handle may appear once (its scratch is per handle)"); return BLU_ERR_INVALID_ARG; }
+        if (taxes[i]->n_tax != taxes[0]->n_tax) { set_error("handles of different taxonomies"); return BLU_ERR_INVALID_ARG; }
+    }
+    if (hits->n_queries == 0) return BLU_OK;
+    if (!out || !hits->seg_off) { set_error("null output or seg_off"); return BLU_ERR_INVALID_ARG; }
+    for (uint64_t q = 0; q < hits->n_queries; ++q)
+        if (hits->seg_off[q] > hits->seg_off[q + 1]) { set_error("seg_off must be ascending for a sharded run"); return BLU_ERR_INVALID_ARG; }
+    std::vector<uint64_t> bounds(n + 1);
+    int rc = blu_shard_ranges(hits->seg_off, hits->n_queries, n, bounds.data());
+    if (rc != BLU_OK) return rc;
+    std::vector<int> rcs(n, BLU_OK);
+    std::vector<std::string> errs(n);
+    std::vector<std::thread> pool;
+    for (uint32_t i = 0; i < n; ++i)
+        pool.emplace_back([&, i]() {
+            const uint64_t q0 = bounds[i], q1 = bounds[i + 1];
+            if (q1 == q0) return;
+            const uint64_t r0 = hits->seg_off[q0], r1 = hits->seg_off[q1];
+            std::vector<uint64_t> seg(q1 - q0 + 1);
+            for (uint64_t q = q0; q <= q1; ++q) seg[q - q0] = hits->seg_off[q] - r0;      // offsets rebased to the slice
+            blu_hits h = *hits;
+            h.bitscore = hits->bitscore + r0; h.tax_row = hits->tax_row + r0; h.align_len = hits->align_len + r0;
+            h.acc_rank = hits->acc_rank + r0;
+            h.pident = hits->pident ? hits->pident + r0 : nullptr;
+            h.pident_milli = hits->pident_milli ? hits->pident_milli + r0 : nullptr;
+            h.seg_off = seg.data(); h.n_hits = r1 - r0; h.n_queries = q1 - q0;
+            blu_run_params p = *params;
+            p.stream = nullptr;                                                          // each shard on its device's null stream
+            rcs[i] = blu_consensus_run(taxes[i], &h, &p, out + q0);
+            if (rcs[i] != BLU_OK) { char b[512]; blu_last_error(b, sizeof b); errs[i] = b; return; }
+            for (uint64_t q = q0; q < q1; ++q)                                           // reference rows -> rows of the whole table
+                if (out[q].ref_row != 0xFFFFFFFFu) out[q].ref_row += (uint32_t)r0;
+        });
+    for (auto& th : pool) th.join();
+    for (uint32_t i = 0; i < n; ++i)
+        if (rcs[i] != BLU_OK) { set_error("shard %u: %s", i, errs[i].c_str()); return rcs[i]; }
+    return BLU_OK;
 }
 
 int blu_consensus_last_launch(char* kernel_name, size_t len, uint32_t* grid, uint32_t* block) {

@@ -183,6 +183,45 @@ def run_consensus_host(tax: Taxonomy, seg_off, bitscore, tax_row, pident, align_
     return out
 
 
+def shard_ranges(seg_off, n_shards: int) -> np.ndarray:
+    """blu_shard_ranges: query bounds of n_shards contiguous ranges balanced by hit count."""
+    seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
+    bounds = np.zeros(n_shards + 1, dtype=np.uint64)
+    rc = N.lib().blu_shard_ranges(seg.ctypes.data_as(C.c_void_p), C.c_uint64(len(seg) - 1), C.c_uint32(n_shards),
+                                  bounds.ctypes.data_as(C.c_void_p))
+    if rc != N.BLU_OK:
+        raise N.BluError(rc, "blu_shard_ranges")
+    return bounds
+
+
+def run_consensus_multi(taxes: Sequence[Taxonomy], seg_off, bitscore, tax_row, pident, align_len, acc_rank,
+                        strategy: str = "relaxed", pident_milli=None) -> np.ndarray:
+    """blu_consensus_run_multi: one host table over several handles of the same taxonomy (one per GPU); `tax_row` holds
+    engine row ids (identical for every handle of one taxonomy)."""
+    seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
+    bs = np.ascontiguousarray(bitscore, dtype=np.int32)
+    tx = np.ascontiguousarray(tax_row)
+    tx = tx.view(np.uint32) if tx.dtype == np.int32 else np.ascontiguousarray(tx, dtype=np.uint32)
+    pid = np.ascontiguousarray(pident, dtype=np.float64) if pident_milli is None else None
+    pm = np.ascontiguousarray(pident_milli, dtype=np.uint32) if pident_milli is not None else None
+    aln = np.ascontiguousarray(align_len, dtype=np.int32)
+    ac = np.ascontiguousarray(acc_rank)
+    ac = ac.view(np.uint32) if ac.dtype == np.int32 else np.ascontiguousarray(ac, dtype=np.uint32)
+    nq, nh = len(seg) - 1, int(seg[-1])
+    hits = N.Hits(bs.ctypes.data, tx.ctypes.data, pid.ctypes.data if pm is None else None, aln.ctypes.data, ac.ctypes.data,
+                  seg.ctypes.data, nh, nq, 0, 0, pm.ctypes.data if pm is not None else None)
+    params = N.RunParams(N.STRATEGY[strategy], 0, None)
+    out = np.zeros(nq, dtype=RESULT_DTYPE)
+    handles = (C.c_void_p * len(taxes))(*[t.handle for t in taxes])
+    L = N.lib()
+    L.blu_consensus_run_multi.restype = C.c_int
+    L.blu_consensus_run_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.blu_consensus_run_multi(handles, len(taxes), C.byref(hits), C.byref(params), out.ctypes.data)
+    if rc != N.BLU_OK:
+        raise N.BluError(rc, "blu_consensus_run_multi")
+    return out
+
+
 def run_consensus_device(tax: Taxonomy, hits: dict, out, strategy: str = "relaxed", stream: Optional[int] = None):
     """torch CUDA tensors in (`hits` keys: seg_off bitscore tax_row align_len acc_rank and either pident (float64) or
     pident_milli (int32 bit pattern of uint32)), records into the uint8 CUDA tensor `out` of 32 * n_queries bytes.

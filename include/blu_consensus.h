@@ -187,9 +187,21 @@ int blu_taxonomy_row_map(const blu_taxonomy* tax, uint32_t* out_map, uint32_t* o
  * device when hits->on_device, else on the host.  Asynchronous on
  * params->stream when on_device (no host sync inside); synchronous otherwise.
  * Consecutive runs on one handle must be ordered (same stream, or synchronised): the handle's scratch
- * (worklist, alternating counters) is reused from run to run. */
+ * (worklist and its counters) is reused from run to run. */
 int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_run_params* params,
                       blu_result* out);
+
+/* One host table over several GPUs: `taxes[0..n_tax_handles)` are handles of the SAME taxonomy and cutoff
+ * configuration on different devices (the same device twice is allowed).  Queries are cut into contiguous ranges
+ * balanced by hit count (blu_shard_ranges), every range runs on its handle from a host thread of its own (staging,
+ * kernels and record copy-back overlap across devices), and the records land in `out` in query order with `ref_row`
+ * pointing into the whole table.  Host pointers only (hits->on_device must be 0); no collective, nothing shared but
+ * the read-only inputs.  Returns the first error of any shard. */
+int blu_consensus_run_multi(const blu_taxonomy* const* taxes, uint32_t n_tax_handles, const blu_hits* hits,
+                            const blu_run_params* params, blu_result* out);
+/* bounds[0..n_shards]: query indices cutting seg_off[0..n_queries] into n_shards contiguous ranges whose hit counts
+ * are as equal as the segment boundaries allow (host pointers). */
+int blu_shard_ranges(const uint64_t* seg_off, uint64_t n_queries, uint32_t n_shards, uint64_t* bounds);
 
 /* Name of the dominant kernel and its launch geometry for the last run on this
  * thread (for profiles/ bookkeeping). */

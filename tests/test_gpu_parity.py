@@ -329,3 +329,23 @@ def test_hostile_offsets_and_row_ids_do_not_disturb_valid_queries():
     intact[qid] = False
     assert intact.sum() > 300 and out2[intact].tobytes() == clean[intact].tobytes()
     assert set(np.unique(out2["status"])) <= {0, 1, 2, 16, 17, 18, 19, 20}
+
+
+def test_sharded_run_over_several_handles_equals_the_single_run():
+    """blu_consensus_run_multi: contiguous query ranges balanced by hit count, one handle and host thread per range,
+    records in query order with table-wide reference rows (two and three handles on the one GPU of the test box)."""
+    tax = synth.make_taxonomy(30000, synth.SEEDS["C5"], deep=True)
+    dh = synth.make_hits(tax, 20000, synth.SEEDS["C5"], None, zipf=(1.1, 1, 2000), device="cuda")
+    h = dh.numpy()
+    handles = [_engine_tax(tax, "bacteria") for _ in range(3)]
+    rows = handles[0].engine_rows(h["tax_row"])
+    single = engine.run_consensus_host(handles[0], h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], "cautious")
+    _assert_records_equal(single, H.columnar(tax, h, "bacteria", "cautious", threads=8))
+    for n in (2, 3):
+        multi = engine.run_consensus_multi(handles[:n], h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], "cautious")
+        assert multi.tobytes() == single.tobytes()
+    milli = engine.run_consensus_multi(handles, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], "cautious",
+                                       pident_milli=dh.pident_milli.cpu().numpy())
+    assert milli.tobytes() == single.tobytes()
+    with pytest.raises(N.BluError):   # one handle twice: its scratch is per handle
+        engine.run_consensus_multi([handles[0], handles[0]], h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"])

@@ -156,3 +156,18 @@ def test_no_cpu_fallback():
         with pytest.raises(N.BluError) as e2:
             engine.Taxonomy(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, device=0)
         assert e2.value.code == N.BLU_ERR_NO_DEVICE
+
+
+def test_shard_ranges_match_the_python_sharding():
+    """blu_shard_ranges (C ABI, used by blu_consensus_run_multi) cuts like blutils_amd.shard.balanced_query_ranges."""
+    from blutils_amd import engine, shard
+    rng = np.random.default_rng(4)
+    for trial in range(40):
+        nq = int(rng.integers(1, 400))
+        counts = rng.integers(0, 60, nq) if trial % 3 else (rng.zipf(1.3, nq) % 3000)
+        seg = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        for parts in (1, 2, 3, 8, 13):
+            got = engine.shard_ranges(seg, parts)
+            exp = shard.balanced_query_ranges(seg, parts)
+            assert [(int(got[i]), int(got[i + 1])) for i in range(parts)] == exp
+            assert got[0] == 0 and got[-1] == nq and np.all(np.diff(got.astype(np.int64)) >= 0)
