@@ -115,3 +115,29 @@ def test_pipeline_document_is_the_same_with_either_parser(tmp_path, force_gpu):
     for r in a + b:
         r["runId"] = None
     assert a == b and sum(r["taxon"] is not None for r in a) > 1000
+
+
+def test_garbage_input_is_refused_like_on_the_cpu(tmp_path, force_gpu):
+    """Arbitrary bytes must not fault the GPU parser: it declines and the CPU parser reports its usual error."""
+    rng = np.random.default_rng(9)
+    tj = _db(tmp_path)
+    good = "\n".join(_rows(200, 4, rng)) + "\n"
+    variants = {
+        "random_bytes": bytes(rng.integers(0, 256, 200000, dtype=np.uint8)),
+        "no_newline_at_all": b"x" * 100000,
+        "only_newlines": b"\n" * 5000,
+        "truncated_mid_line": good.encode()[: len(good) // 2 - 7],
+        "nul_bytes": good.replace("\t400\t", "\t4\x000\t", 3).encode(),
+        "huge_field": (good + "q\t" + "A" * (1 << 21) + "\t100\t99.0\t400\t0\t0\t1\t400\t1\t400\t1e-5\t50\n").encode(),
+    }
+    for name, blob in variants.items():
+        f = tmp_path / f"{name}.tsv"
+        f.write_bytes(blob)
+        outcome = []
+        for dev in (-1, 0):
+            try:
+                st, ck = pipeline.ingest_only(str(f), tj, False, device=dev)
+                outcome.append(("ok", st["n_hits"], ck))
+            except N.BluError as e:
+                outcome.append(("error", e.code))
+        assert outcome[0] == outcome[1], (name, outcome)
