@@ -26,10 +26,13 @@ struct RankInfo {
 //
 // Lineage rows sit in LEXICOGRAPHIC order of their node sequences (row index = "pos"; engine row ids are
 // pos | lineage length << BLU_ROW_BITS, so the streaming phase needs no taxonomy lookup).  One row:
-//   word 0      len | shape << 8        (len 0 = lineage that fails parse_taxonomy)
-//   word 1+j    node id of level j      interned (Display(rank), identifier)
-// i.e. 64 bytes (half a cache line: one 64-byte memory request) for lineages of up to 15 levels; stride = 16 words
-// per 16 levels.  What the finalisation needs per LEVEL — cutoff, rank code, max-allowed-rank code — depends on the
+//   word 0             len | shape << 8   (len 0 = lineage that fails parse_taxonomy)
+//   bytes 4+2j, 5+2j   (a_j, b_j), j < 20: how many sorted rows to the left / right of this one still share its levels
+//                      0..j, saturated at 255.  The levels shared by a group spanning [lo, hi] around this row are the
+//                      levels with a_j >= pos - lo and b_j >= hi - pos (exact when both distances are < 255; wider
+//                      groups, and agreement deeper than 20 levels, use the lcp8 / rmq tables below)
+//   word 11+j          node id of level j   interned (Display(rank), identifier)
+// i.e. one 128-byte line for lineages of up to 20 levels (stride 32 words; deeper taxonomies get longer rows).  What the finalisation needs per LEVEL — cutoff, rank code, max-allowed-rank code — depends on the
 // row's shape only: codes[shape][cstride], one word per level =
 //   cutoff id (12 bits) | canonical rank code (10 bits) << 12 | max-allowed-rank code (10 bits) << 22
 // (a few hundred KB, re-read by every query, so it stays in L2).  Cutoffs are stored by id into `cutvals`, the
@@ -47,10 +50,13 @@ struct TaxDev {
     const double* cutvals;   // [n_cutvals] distinct cutoff values (NaN included, compared by bit pattern)
     uint32_t n_cutvals;
     uint64_t n_tax;
-    uint32_t stride;         // words per lineage row, multiple of 16 (64 bytes)
+    uint32_t stride;         // words per lineage row, multiple of 32 (128 bytes)
+    uint32_t node_base;      // word of the row where the node ids start (BLU_ROW_NODE_BASE)
     uint32_t max_depth;      // longest lineage: bounds the length bits of a (possibly corrupt) row id
 };
 
+#define BLU_ROW_IV_LEVELS 20u    // levels whose neighbour run lengths sit in the row (words 1..10)
+#define BLU_ROW_NODE_BASE 11u    // first node-id word of a row
 #define BLU_PACK_CUT_BITS 12u
 #define BLU_PACK_CODE_BITS 10u
 #define BLU_PACK_CODE_MASK ((1u << BLU_PACK_CODE_BITS) - 1u)
@@ -106,7 +112,8 @@ struct blu_taxonomy {
     double* d_cutvals = nullptr;
     uint32_t* d_codes = nullptr;
     uint32_t n_cutvals = 0;
-    uint32_t dev_stride = 16;                // words per DEVICE row (= stride: the device rows are the sorted host rows)
+    uint32_t dev_stride = 32;                // words per DEVICE row
+    uint32_t node_base = 1;                  // see TaxDev
     uint64_t device_bytes = 0;
     // per-handle scratch of the run call (worklist of long / overflowing queries); grown on demand,
     // so one handle must not be used by two concurrent blu_consensus_run calls

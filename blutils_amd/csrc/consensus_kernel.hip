@@ -443,7 +443,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         const uint64_t q = q0 + (uint32_t)lane;
         const uint32_t row0 = (uint32_t)my_off;
         // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
-        uint32_t mode = 3, r_len = 0, r_row = 0, r_pos = 0, r_hdr = 0, minlen = 0, d = 0, rec_kind = 0;
+        uint32_t mode = 3, r_len = 0, r_row = 0, r_pos = 0, r_hdr = 0, minlen = 0, d = 0, rec_kind = 0, g_lo = 0, g_hi = 0;
         typedef typename PidKey<PID32>::type PK;
         PK r_pid = 0, max_pid = 0;   // fold(0.0, max): find_multi_taxa_consensus.rs:182-185
         uint4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
@@ -493,19 +493,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                         r_pos = take ? (x.pq & 0xFF) : r_pos;
                     }
                     mode = k == 1 ? 2u : 0u;
-#ifdef BLU_EXP_EARLY_HDR
-                    // start the reference row's fetch now (header word = shape id; the identifier sits in the same
-                    // 64-byte row): it overlaps the range-minimum lookups below instead of following them
-                    r_hdr = t.lin[(uint64_t)r_row * t.stride];
-#endif
-                    // levels shared by the whole group (:137-180): every row agrees with the reference row on exactly
-                    // the levels all rows share, and the scan never looks past the shortest lineage
-                    d = minlen;
-#ifdef BLU_EXP_NORMQ
-                    if (k > 1 && lo < hi) d = umin(minlen, 1u + ((hi - lo) & 3u));
-#else
-                    if (k > 1 && lo < hi) d = umin(minlen, shared_levels(t, lo, hi));
-#endif
+                    g_lo = lo; g_hi = hi;    // span of the group in sorted order: phase 2c turns it into the shared levels
                 }
             }
         }
@@ -518,25 +506,46 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         if (mode != 3) {
 #endif
             const bool single = mode == 2;
-            const bool agree = single | (d >= minlen);
             rec_kind = 1;
+            // The reference row: header, neighbour run lengths of 20 levels and the node ids in one 128-byte line (up to 20
+            // levels), read with eight 16-byte loads issued back to back: one memory request.  (Reading the node id
+            // later, after the codes lookup, fetched the line a second time for half of the queries: the stream had
+            // pushed it out of L2 in between.)  Per-level cutoff ids and rank codes come from the row of the shape in
+            // the codes table (L2-resident).
+#ifdef BLU_EXP_NOREF
+            const uint32_t* ref = t.lin;
+#else
+            const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
+#endif
+            const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
+            uint4 w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = ref4[k];
+            r_hdr = w[0].x;   // (requesting it back in phase 2a costs a second fetch: the line leaves L2 in between)
+            // its length field equals the id's for a well-formed id and bounds the loops for a corrupt one
+            const uint32_t len_ref = umin(r_len, r_hdr & 0xFF);
+            // levels shared by the whole group (find_multi_taxa_consensus.rs:137-180): every row agrees with the reference
+            // row on exactly the levels all rows of the span share, and the scan never looks past the shortest lineage
+            d = minlen;
+            if (!single && g_lo < g_hi) {
+                const uint32_t dl = r_row - g_lo, dh = g_hi - r_row;     // lo <= reference row <= hi
+                bool by_table = dl >= 255u || dh >= 255u;               // saturated run lengths: not decidable from the row
+                if (!by_table) {
+                    const uint32_t iw[10] = {w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w, w[2].x, w[2].y, w[2].z};
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < BLU_ROW_IV_LEVELS; ++j) {
+                        const uint32_t pair = (iw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                        cnt += (uint32_t)((j < len_ref) & ((pair & 0xFFu) >= dl) & ((pair >> 8) >= dh));   // monotone in j
+                    }
+                    if (cnt >= BLU_ROW_IV_LEVELS && minlen > BLU_ROW_IV_LEVELS) by_table = true;   // agreement deeper than the row's run lengths
+                    else d = umin(minlen, cnt);
+                }
+                if (by_table) d = umin(minlen, shared_levels(t, g_lo, g_hi));
+            }
+            const bool agree = single | (d >= minlen);
             if (!agree && d == 0) pack_status(ra, rb, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
             else {
-                // The reference row (header + node ids) is 64 bytes for up to 15 levels: four 16-byte loads issued back
-                // to back = one 64-byte memory request.  Per-level cutoff ids and rank codes come from the row of its
-                // shape in the codes table (L2-resident: a few hundred KB re-read by every query).
-#ifdef BLU_EXP_NOREF
-                const uint32_t* ref = t.lin;
-#else
-                const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
-#endif
-                const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
-                uint4 w[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) w[k] = ref4[k];
-                r_hdr = w[0].x;   // (requesting it back in phase 2a costs a second fetch: the line leaves L2 in between)
-                // its length field equals the id's for a well-formed id and bounds the loops for a corrupt one
-                const uint32_t len_ref = umin(r_len, r_hdr & 0xFF);
                 const uint32_t* codes = t.codes + (uint64_t)(r_hdr >> 8) * t.cstride;
                 const uint4* codes4 = reinterpret_cast<const uint4*>(codes);
                 const uint32_t b = single ? len_ref : (agree ? minlen - 1 : d - 1);
@@ -567,14 +576,14 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     const uint4 x = codes4[k];
                     level(4 * k, x.x); level(4 * k + 1, x.y); level(4 * k + 2, x.z); level(4 * k + 3, x.w);
                 }
-                // node id of level j: words 1..15 are in registers, deeper levels are read from the row
-                const uint32_t nid[16] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w,
-                                          w[2].x, w[2].y, w[2].z, w[2].w, w[3].x, w[3].y, w[3].z, w[3].w};
+                // node id of level j: words 11..30 of the line are in registers, deeper levels are read from the row
+                const uint32_t nid[20] = {w[2].w, w[3].x, w[3].y, w[3].z, w[3].w, w[4].x, w[4].y, w[4].z, w[4].w, w[5].x,
+                                          w[5].y, w[5].z, w[5].w, w[6].x, w[6].y, w[6].z, w[6].w, w[7].x, w[7].y, w[7].z};
                 auto node_of = [&](uint32_t j) {
                     uint32_t v = 0;
-                    if (j >= 15) v = ref[1 + j];
+                    if (j >= 20) v = ref[BLU_ROW_NODE_BASE + j];
 #pragma unroll
-                    for (uint32_t i = 1; i < 16; ++i) v = (j + 1 == i) ? nid[i] : v;
+                    for (uint32_t i = 0; i < 20; ++i) v = (j == i) ? nid[i] : v;
                     return v;
                 };
                 if (agree) A = F;                                                  // single hit / single-flag branch (:74-75)
@@ -831,7 +840,7 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
         const bool in_l = (uint32_t)lane < len_ref;
         const uint32_t lvl = in_l ? (uint32_t)lane : 0u;
         const uint32_t shape_ref = t.lin[(uint64_t)row_ref * t.stride] >> 8;
-        const uint32_t ref_node = t.lin[(uint64_t)row_ref * t.stride + 1 + lvl];
+        const uint32_t ref_node = t.lin[(uint64_t)row_ref * t.stride + BLU_ROW_NODE_BASE + lvl];
         const uint32_t packed = t.codes[(uint64_t)shape_ref * t.cstride + lvl];
         const double cut = t.cutvals[packed & ((1u << BLU_PACK_CUT_BITS) - 1u)];
         const uint32_t codes = packed_rank(packed) | (packed_mar(packed) << 16);

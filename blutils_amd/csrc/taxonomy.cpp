@@ -297,9 +297,7 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
     };
     // device rows = the sorted host rows (header, node ids): 64 bytes for lineages of up to 15 levels; the per-level
     // cutoff ids and rank codes depend on the shape only and live in a small table of their own (dev_codes)
-    tax->dev_stride = stride;
-    std::vector<uint32_t>& dev_rows = lin_sorted;
-    if (dev_rows.size() < 32) dev_rows.resize(32, 0u);
+    // (the rows themselves are laid out further down, once the adjacent-row LCPs are known)
     std::vector<uint32_t> dev_codes(std::max<size_t>((size_t)tax->n_shapes * tax->sc, 16), 0u);
     for (size_t k = 0; k < (size_t)tax->n_shapes * tax->sc; ++k) {
         const uint32_t code = tax->h_codes[k];
@@ -321,6 +319,46 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         uint32_t c = 0;
         while (c < m && ra[1 + c] == rb[1 + c]) ++c;
         lcp8[i] = (uint8_t)c;
+    }
+    // Device rows: word 0 = len | shape << 8; words 1..10 = for each of the first 20 levels a byte pair (a_j, b_j) = how
+    // many sorted rows to the left / right of this row still share its levels 0..j, saturated at 255; words 11.. = the
+    // node ids.  With them the levels shared by a group spanning [lo, hi] around row r are the levels with
+    // a_j >= r - lo and b_j >= hi - r — exact whenever both distances are below 255, which is the common case (the group
+    // sits inside one genus or family); wider groups, and agreement deeper than 20 levels, use the range-minimum
+    // tables.  One 128-byte line holds it all for lineages of up to 20 levels.
+    const uint32_t D = std::max<uint32_t>(tax->max_depth, 1);
+    const uint32_t node_base = BLU_ROW_NODE_BASE;
+    const uint32_t dstride = ((node_base + D + 31) / 32) * 32;
+    tax->dev_stride = dstride;
+    tax->node_base = node_base;
+    std::vector<uint32_t> dev_rows(std::max<size_t>((size_t)n * dstride, 32), 0u);
+    {
+        std::vector<uint32_t> run(D, 0);        // run[j] = start (left pass) / end (right pass) of the current run at level j
+        for (uint64_t r = 0; r < n; ++r) {
+            const uint32_t* src = &lin_sorted[(size_t)r * stride];
+            uint32_t* dst = &dev_rows[(size_t)r * dstride];
+            const uint32_t len = src[0] & 0xFF;
+            dst[0] = src[0];
+            for (uint32_t j = 0; j < len; ++j) dst[node_base + j] = src[1 + j];
+            const uint32_t shared = r > 0 ? lcp8[r - 1] : 0;          // levels shared with the previous row
+            uint8_t* ab = reinterpret_cast<uint8_t*>(dst + 1);
+            for (uint32_t j = 0; j < len; ++j) {
+                if (j >= shared) run[j] = (uint32_t)r;                   // a new run starts here at level j
+                if (j < BLU_ROW_IV_LEVELS) ab[2 * j] = (uint8_t)std::min<uint64_t>(r - run[j], 255);
+            }
+            for (uint32_t j = len; j < D; ++j) run[j] = (uint32_t)r + 1; // levels this row does not have break the runs
+        }
+        for (uint64_t r = n; r-- > 0;) {
+            uint32_t* dst = &dev_rows[(size_t)r * dstride];
+            const uint32_t len = dst[0] & 0xFF;
+            const uint32_t shared = r + 1 < n ? lcp8[r] : 0;           // levels shared with the next row
+            uint8_t* ab = reinterpret_cast<uint8_t*>(dst + 1);
+            for (uint32_t j = 0; j < len; ++j) {
+                if (j >= shared) run[j] = (uint32_t)r;
+                if (j < BLU_ROW_IV_LEVELS) ab[2 * j + 1] = (uint8_t)std::min<uint64_t>(run[j] - r, 255);
+            }
+            for (uint32_t j = len; j < D; ++j) run[j] = (uint32_t)r;   // (never read before being reset: j >= shared for the next row)
+        }
     }
     uint32_t levels = 1;
     while ((1u << levels) <= nb) ++levels;
