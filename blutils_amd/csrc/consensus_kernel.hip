@@ -756,21 +756,26 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
         for (uint64_t sb = 0; sb < n && err_status == 0; sb += LONG_SPAN) {
         const uint32_t ns = (n - sb) < LONG_SPAN ? (uint32_t)(n - sb) : LONG_SPAN;
         const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(c_bs + sb), 0, ns * 4u, 0x00020000);
-        for (uint32_t base4 = 0; base4 < ns && err_status == 0; base4 += 4 * WAVE) {
-          // the bit-scores of four 64-row chunks are fetched together; top rows are sparse, so most chunks end at the ballot
-          int pre[4];
+        for (uint32_t base = 0; base < ns && err_status == 0; base += 1024) {
+          // 1024 rows per round trip, as in pass 1 (four 16-byte loads per lane in flight); top rows are sparse, so most of
+          // the sixteen 64-row groups end at the ballot.  Lane l holds rows base + 256 u + 4 l + c: a lane sees its rows
+          // in file order, which is all the running selects below need (ties across lanes are settled by row index).
+          u32x4 v[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) pre[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_b, (base4 + u * WAVE + (uint32_t)lane) * 4u, 0, 0);
-#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
+          uint32_t it_err_row = 0xFFFFFFFFu, it_err_status = 0;   // first failing row of this round trip, in file order
           for (int u = 0; u < 4; ++u) {
-            const uint32_t base = (uint32_t)sb + base4 + u * WAVE;   // row index inside the segment
-            if (base4 + u * WAVE >= ns || err_status != 0) break;
-            const uint32_t i = base + (uint32_t)lane;
-            const bool act = i < n && base4 + u * WAVE + (uint32_t)lane < ns;
-            const bool top = act && pre[u] == M;
+            if (base + (uint32_t)u * 256 >= ns) break;
+            const u32x4 cur = u == 0 ? v[0] : (u == 1 ? v[1] : (u == 2 ? v[2] : v[3]));
+            const uint32_t vv[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+            const uint32_t iloc = base + (uint32_t)u * 256 + (uint32_t)lane * 4u + (uint32_t)c;
+            const bool top = iloc < ns && (int)vv[c] == M;
             const uint64_t mask = __ballot(top);
             if (!mask) continue;
             k += (uint32_t)__builtin_popcountll(mask);
+            const uint32_t i = (uint32_t)sb + iloc;                   // row index inside the segment
             const uint32_t ii = top ? i : 0;
             const uint32_t tax = c_tax[ii];
             const double pid = PID32 ? milli_to_f64(c_pm[ii]) : c_pid[ii];
@@ -783,9 +788,9 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
             const uint64_t um = __ballot(unmatched), bm = __ballot(bad);
             if (um | bm) {   // parse_taxonomy Err at the first failing row (find_single_query_consensus.rs:58-60)
                 const int fl = first_lane(um | bm);
-                err_status = ((um >> fl) & 1) ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE;
-                err_row = base + fl;
-                break;
+                const uint32_t cand = (uint32_t)sb + base + (uint32_t)u * 256 + (uint32_t)fl * 4u + (uint32_t)c;
+                if (cand < it_err_row) { it_err_row = cand; it_err_status = ((um >> fl) & 1) ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE; }
+                continue;
             }
             const bool take = top & ((have == 0) | key_better<STRAT>(len, pid, aln, acc, b_len, b_pid, b_aln, b_acc));
             have = top ? 1u : have;
@@ -799,7 +804,9 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
             l_lo = top ? umin(l_lo, pos) : l_lo;
             l_hi = (top && pos > l_hi) ? pos : l_hi;
             l_maxpid = (top && pid > l_maxpid) ? pid : l_maxpid;
+            }
           }
+          if (it_err_status) { err_status = it_err_status; err_row = it_err_row; }
         }
         }
         if (err_status) {
