@@ -12,10 +12,12 @@
 //     order into a per-wave LDS list (row id, align_len, accession rank, position,
 //     pident).  The row id carries the lineage length: no taxonomy lookup here.
 //   phase 2a (lane = query, LDS only): parse errors, reference row by the stable-sort
-//     rule, shortest lineage, group-max pident, span in sorted lineage order; the
-//     first disagreeing level is a range minimum over the adjacent-row LCP array.
-//   phase 2c (lane = query): one 128-byte line of the reference row gives the node
-//     ids, per-level cutoff ids (values in LDS) and rank codes; cutoff tests; record.
+//     rule, shortest lineage, group-max pident, span [lo, hi] in sorted lineage order.
+//   phase 2c (lane = query): one 128-byte line of the reference row gives, per level,
+//     how far the neighbouring rows share it (-> the first disagreeing level of the
+//     span; a range minimum over the adjacent-row LCP array for wide spans) and the
+//     node ids; per-level cutoff ids (values in LDS) and rank codes come from the
+//     table row of the lineage's shape; cutoff tests; record.
 //   Records are staged in LDS and leave as one write-through burst per block.
 //   Queries with more than 64 hits, or whose top group does not fit the LDS
 //   list, are appended to a worklist.
@@ -23,7 +25,8 @@
 //   chunked passes over the segment (any length), wave-parallel finalisation.
 //
 // Integer/compare work only: no MFMA.  The roofline is the HBM stream of the
-// five columns (24 B/hit) + 8 B offsets + 32 B record per query.
+// five columns (20 B/hit with the milli-percent perc_identity, 24 B/hit with f64)
+// + 8 B offsets + 32 B record per query.
 // BLU_EXP_* macros are timing-only experiment hooks (scripts/build_variants.sh);
 // the product build defines none of them.
 #include <hip/hip_runtime.h>
