@@ -349,3 +349,60 @@ def test_sharded_run_over_several_handles_equals_the_single_run():
     assert milli.tobytes() == single.tobytes()
     with pytest.raises(N.BluError):   # one handle twice: its scratch is per handle
         engine.run_consensus_multi([handles[0], handles[0]], h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"])
+
+
+def test_maximum_depth_lineages_and_wide_groups():
+    """64-level lineages (BLU_MAX_DEPTH, level-mask bit 63) that agree for 10..63 levels — beyond the 20 levels whose
+    run lengths sit in the reference row — and groups spanning more than 255 sorted rows: both take the range-minimum
+    path of the stream kernel; segments over 64 rows take the worklist kernel.  Against both oracles."""
+    rng = np.random.default_rng(21)
+    backbone = ["d", "k", "p", "c", "o", "f", "g", "s"]
+    rank_names = backbone + ["clade", "strain"]
+    n_tax = 1500
+    off, node, rank = [0], [], []
+    for t in range(n_tax):
+        depth = 64 if t % 3 else int(rng.integers(9, 64))
+        split = int(rng.integers(10, 64))                       # first level at which this taxon leaves the common trunk
+        fam = t % 5                                             # five trunks: long common prefixes, wide sorted spans
+        for j in range(depth):
+            if j < 8:
+                r = backbone[j]
+            else:
+                r = "strain" if j == depth - 1 else "clade"
+            ident = f"t{fam}_{j}" if j < split else f"x{t}_{j}"
+            if j == 0:
+                ident = "root"
+            node.append((r, ident))
+            rank.append(rank_names.index(r))
+        off.append(len(node))
+    interned = {}
+    node = [interned.setdefault((orc.rank_display(r), i), len(interned)) for r, i in node]
+    tax = synth.SynthTaxonomy(rank_names, np.array(off, np.uint64), np.array(node, np.uint32), np.array(rank, np.uint16),
+                              (100 + np.arange(n_tax)).astype(np.int64), np.zeros((9, n_tax), np.int32), np.zeros((9, n_tax), np.int32),
+                              n_tax, 21, False)
+    n_q = 1500
+    lens = np.where(rng.random(n_q) < 0.1, rng.integers(65, 200, n_q), rng.integers(1, 30, n_q))
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nh = int(seg[-1])
+    qid = np.repeat(np.arange(n_q), lens)
+    same_trunk = (qid % 2 == 0)
+    rows = np.where(same_trunk, (rng.integers(0, n_tax // 5, nh) * 5 + qid % 5) % n_tax, rng.integers(0, n_tax, nh)).astype(np.int32)
+    pident = (rng.integers(80000, 100001, nh) / 1000).astype(np.float64)
+    whole = qid % 10 == 0                                     # one 64-level taxon per query, identity 100: every level passes
+    rows[whole] = (1 + 3 * (qid[whole] % 400)).astype(np.int32)
+    pident[whole] = 100.0
+    hits = {"seg_off": seg, "bitscore": rng.choice([900, 900, 899], nh).astype(np.int32), "tax_row": rows,
+            "pident": pident,
+            "align_len": rng.integers(380, 480, nh).astype(np.int32), "acc_rank": rng.integers(0, 50, nh).astype(np.int32)}
+    for taxon, custom in (("bacteria", None), ("custom", H.CUSTOM_16S)):
+        t = _engine_tax(tax, taxon, custom)
+        assert t.max_depth == 64
+        for strategy in ("relaxed", "cautious"):
+            got = _run_host(t, hits, strategy)
+            _assert_records_equal(got, H.columnar(tax, hits, taxon, strategy, custom))
+    assert (got["level_mask"] >> np.uint64(63)).any()               # the deepest level is reached by somebody
+    assert ((got["status"] == 0) & (got["bean_index"] >= 20)).any() # agreement deeper than the row's run lengths
+    faithful = orc.run(H.oracle_table(tax, hits), taxon="custom", strategy="cautious", custom=H.CUSTOM_16S, threads=4).results()
+    r = _engine_renderer(t, tax, hits)
+    for q in range(len(got)):
+        H.assert_matches_faithful(r.render(got[q]), faithful[q], q)
