@@ -544,7 +544,9 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     if (cnt >= BLU_ROW_IV_LEVELS && minlen > BLU_ROW_IV_LEVELS) by_table = true;   // agreement deeper than the row's run lengths
                     else d = umin(minlen, cnt);
                 }
+#ifndef BLU_EXP_NOTAB
                 if (by_table) d = umin(minlen, shared_levels(t, g_lo, g_hi));
+#endif
             }
             const bool agree = single | (d >= minlen);
             if (!agree && d == 0) pack_status(ra, rb, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
