@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <algorithm>
@@ -63,46 +64,113 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count);
     }
 
-    // host pointers: stage over PCIe, run, copy the records back (synchronous)
+    // host pointers: stage over PCIe, run, copy the records back (synchronous).  The table goes over in chunks of whole
+    // queries, double-buffered: while the kernels of chunk k run on one stream, chunk k+1 is copied on the other (the
+    // handle's worklist is shared, so the kernels themselves are chained by an event).  A table that fits is one chunk.
     int rc = BLU_OK;
-    hipStream_t s = (hipStream_t)params->stream;
     const size_t nh = hits->n_hits, nq = hits->n_queries;
-    void *d_bs = nullptr, *d_tax = nullptr, *d_pid = nullptr, *d_aln = nullptr, *d_acc = nullptr, *d_seg = nullptr, *d_out = nullptr;
+    const bool milli = hits->pident_milli != nullptr;
+    const size_t row_bytes = milli ? 20 : 24;
+    size_t chunk_rows = nh;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t budget = free_b / 5 * 2 / row_bytes;          // two buffer sets within 80 % of what is free
+            if (budget < chunk_rows) chunk_rows = budget;
+        }
+        if (const char* env = getenv("BLU_STAGE_ROWS")) { const size_t v = (size_t)strtoull(env, nullptr, 10); if (v && v < chunk_rows) chunk_rows = v; }
+    }
+    // chunk boundaries (whole queries, greedy); a table cut into chunks needs an ascending offset table
+    std::vector<uint64_t> cuts{0};
+    size_t max_rows = 0, max_q = 0;
+    if (chunk_rows >= nh) { cuts.push_back(nq); max_rows = nh; max_q = nq; }
+    else {
+        for (uint64_t q = 0; q < nq; ++q)
+            if (hits->seg_off[q] > hits->seg_off[q + 1] || hits->seg_off[q + 1] > nh) { set_error("seg_off must be ascending and within n_hits for a table staged in chunks"); return BLU_ERR_INVALID_ARG; }
+        uint64_t q0 = 0;
+        while (q0 < nq) {
+            uint64_t q1 = q0 + 1;
+            const uint64_t r0 = hits->seg_off[q0];
+            // as many whole queries as fit; a single query longer than the chunk gets a chunk of its own
+            const uint64_t* it = std::upper_bound(hits->seg_off + q0 + 1, hits->seg_off + nq + 1, r0 + chunk_rows);
+            if ((uint64_t)(it - hits->seg_off) - 1 > q1) q1 = (uint64_t)(it - hits->seg_off) - 1;
+            cuts.push_back(q1);
+            max_rows = std::max<size_t>(max_rows, hits->seg_off[q1] - r0);
+            max_q = std::max<size_t>(max_q, q1 - q0);
+            q0 = q1;
+        }
+    }
+    const size_t n_chunks = cuts.size() - 1;
+    const int n_sets = n_chunks > 1 ? 2 : 1;
+    struct Set { void *bs = nullptr, *tax = nullptr, *pid = nullptr, *aln = nullptr, *acc = nullptr, *seg = nullptr, *out = nullptr; hipStream_t s = nullptr; std::vector<uint64_t> seg_host; uint64_t q0 = 0, q1 = 0, r0 = 0; bool busy = false; };
+    Set sets[2];
+    hipEvent_t kernels_done = nullptr;
+    auto finish = [&](Set& st) -> int {      // wait for the chunk in this set, point its records at rows of the whole table
+        if (!st.busy) return BLU_OK;
+        st.busy = false;
+        if (hipStreamSynchronize(st.s) != hipSuccess) { set_error("HIP error while waiting for a staged chunk"); return BLU_ERR_HIP; }
+        if (st.r0)
+            for (uint64_t q = st.q0; q < st.q1; ++q)
+                if (out[q].ref_row != 0xFFFFFFFFu) out[q].ref_row += (uint32_t)st.r0;
+        return BLU_OK;
+    };
     {
         const size_t pad = 64;  // keeps zero-length columns allocatable
-        HIP_TRY(hipMalloc(&d_bs, nh * 4 + pad));
-        HIP_TRY(hipMalloc(&d_tax, nh * 4 + pad));
-        const bool milli = hits->pident_milli != nullptr;
-        HIP_TRY(hipMalloc(&d_pid, nh * (milli ? 4 : 8) + pad));
-        HIP_TRY(hipMalloc(&d_aln, nh * 4 + pad));
-        HIP_TRY(hipMalloc(&d_acc, nh * 4 + pad));
-        HIP_TRY(hipMalloc(&d_seg, (nq + 1) * 8));
-        HIP_TRY(hipMalloc(&d_out, nq * sizeof(blu_result)));
-        if (nh) {
-            HIP_TRY(hipMemcpyAsync(d_bs, hits->bitscore, nh * 4, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpyAsync(d_tax, hits->tax_row, nh * 4, hipMemcpyHostToDevice, s));
-            if (milli) HIP_TRY(hipMemcpyAsync(d_pid, hits->pident_milli, nh * 4, hipMemcpyHostToDevice, s));
-            else HIP_TRY(hipMemcpyAsync(d_pid, hits->pident, nh * 8, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpyAsync(d_aln, hits->align_len, nh * 4, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpyAsync(d_acc, hits->acc_rank, nh * 4, hipMemcpyHostToDevice, s));
+        for (int k = 0; k < n_sets; ++k) {
+            Set& st = sets[k];
+            HIP_TRY(hipMalloc(&st.bs, max_rows * 4 + pad));
+            HIP_TRY(hipMalloc(&st.tax, max_rows * 4 + pad));
+            HIP_TRY(hipMalloc(&st.pid, max_rows * (milli ? 4 : 8) + pad));
+            HIP_TRY(hipMalloc(&st.aln, max_rows * 4 + pad));
+            HIP_TRY(hipMalloc(&st.acc, max_rows * 4 + pad));
+            HIP_TRY(hipMalloc(&st.seg, (max_q + 1) * 8));
+            HIP_TRY(hipMalloc(&st.out, std::max<size_t>(max_q, 1) * sizeof(blu_result)));
+            if (n_chunks > 1) HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+            else st.s = (hipStream_t)params->stream;
         }
-        HIP_TRY(hipMemcpyAsync(d_seg, hits->seg_off, (nq + 1) * 8, hipMemcpyHostToDevice, s));
-        HitsDev hd{(const int32_t*)d_bs, (const uint32_t*)d_tax, milli ? nullptr : (const double*)d_pid,
-                   milli ? (const uint32_t*)d_pid : nullptr, (const int32_t*)d_aln,
-                   (const uint32_t*)d_acc, (const uint64_t*)d_seg, hits->n_hits, hits->n_queries};
-        rc = launch_consensus(td, hd, params->strategy, (blu_result*)d_out, s, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count);
-        if (rc != BLU_OK) goto done;
-        HIP_TRY(hipMemcpyAsync(out, d_out, nq * sizeof(blu_result), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        if (n_chunks > 1) HIP_TRY(hipEventCreateWithFlags(&kernels_done, hipEventDisableTiming));
+        for (size_t c = 0; c < n_chunks; ++c) {
+            Set& st = sets[c % n_sets];
+            rc = finish(st);
+            if (rc != BLU_OK) goto done;
+            st.q0 = cuts[c]; st.q1 = cuts[c + 1];
+            const uint64_t cq = st.q1 - st.q0;
+            st.r0 = n_chunks > 1 ? hits->seg_off[st.q0] : 0;
+            const uint64_t cr = n_chunks > 1 ? hits->seg_off[st.q1] - st.r0 : nh;
+            const uint64_t* seg_src = hits->seg_off + st.q0;
+            if (st.r0) {      // offsets rebased to the chunk
+                st.seg_host.resize(cq + 1);
+                for (uint64_t q = 0; q <= cq; ++q) st.seg_host[q] = hits->seg_off[st.q0 + q] - st.r0;
+                seg_src = st.seg_host.data();
+            }
+            if (cr) {
+                HIP_TRY(hipMemcpyAsync(st.bs, hits->bitscore + st.r0, cr * 4, hipMemcpyHostToDevice, st.s));
+                HIP_TRY(hipMemcpyAsync(st.tax, hits->tax_row + st.r0, cr * 4, hipMemcpyHostToDevice, st.s));
+                if (milli) HIP_TRY(hipMemcpyAsync(st.pid, hits->pident_milli + st.r0, cr * 4, hipMemcpyHostToDevice, st.s));
+                else HIP_TRY(hipMemcpyAsync(st.pid, hits->pident + st.r0, cr * 8, hipMemcpyHostToDevice, st.s));
+                HIP_TRY(hipMemcpyAsync(st.aln, hits->align_len + st.r0, cr * 4, hipMemcpyHostToDevice, st.s));
+                HIP_TRY(hipMemcpyAsync(st.acc, hits->acc_rank + st.r0, cr * 4, hipMemcpyHostToDevice, st.s));
+            }
+            HIP_TRY(hipMemcpyAsync(st.seg, seg_src, (cq + 1) * 8, hipMemcpyHostToDevice, st.s));
+            if (n_chunks > 1 && c > 0) HIP_TRY(hipStreamWaitEvent(st.s, kernels_done, 0));   // the previous chunk's kernels own the worklist
+            HitsDev hd{(const int32_t*)st.bs, (const uint32_t*)st.tax, milli ? nullptr : (const double*)st.pid,
+                       milli ? (const uint32_t*)st.pid : nullptr, (const int32_t*)st.aln,
+                       (const uint32_t*)st.acc, (const uint64_t*)st.seg, cr, cq};
+            rc = launch_consensus(td, hd, params->strategy, (blu_result*)st.out, st.s, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count);
+            if (rc != BLU_OK) goto done;
+            if (n_chunks > 1) HIP_TRY(hipEventRecord(kernels_done, st.s));
+            HIP_TRY(hipMemcpyAsync(out + st.q0, st.out, cq * sizeof(blu_result), hipMemcpyDeviceToHost, st.s));
+            st.busy = true;
+        }
+        for (int k = 0; k < n_sets && rc == BLU_OK; ++k) rc = finish(sets[k]);
     }
 done:
-    if (d_bs) (void)hipFree(d_bs);
-    if (d_tax) (void)hipFree(d_tax);
-    if (d_pid) (void)hipFree(d_pid);
-    if (d_aln) (void)hipFree(d_aln);
-    if (d_acc) (void)hipFree(d_acc);
-    if (d_seg) (void)hipFree(d_seg);
-    if (d_out) (void)hipFree(d_out);
+    for (Set& st : sets) {
+        if (st.busy && st.s) (void)hipStreamSynchronize(st.s);
+        for (void* p : {st.bs, st.tax, st.pid, st.aln, st.acc, st.seg, st.out}) if (p) (void)hipFree(p);
+        if (n_chunks > 1 && st.s) (void)hipStreamDestroy(st.s);
+    }
+    if (kernels_done) (void)hipEventDestroy(kernels_done);
     return rc;
 }
 

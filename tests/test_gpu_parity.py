@@ -406,3 +406,29 @@ def test_maximum_depth_lineages_and_wide_groups():
     r = _engine_renderer(t, tax, hits)
     for q in range(len(got)):
         H.assert_matches_faithful(r.render(got[q]), faithful[q], q)
+
+
+def test_host_table_staged_in_chunks(monkeypatch):
+    """A host table larger than the device budget goes over PCIe in chunks of whole queries, double-buffered on two
+    streams (BLU_STAGE_ROWS forces the cut here): same records, reference rows still table-wide; a single query longer
+    than the chunk gets a chunk of its own."""
+    tax = synth.make_taxonomy(30000, synth.SEEDS["C5"], deep=True)
+    dh = synth.make_hits(tax, 20000, synth.SEEDS["C5"], None, zipf=(1.1, 1, 3000), device="cuda")
+    h = dh.numpy()
+    t = _engine_tax(tax, "bacteria")
+    rows = t.engine_rows(h["tax_row"])
+    whole = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], "relaxed")
+    for stage_rows in (100000, 7919, 1000):
+        monkeypatch.setenv("BLU_STAGE_ROWS", str(stage_rows))
+        cut = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], "relaxed")
+        assert cut.tobytes() == whole.tobytes(), stage_rows
+        cut = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], "relaxed",
+                                        pident_milli=dh.pident_milli.cpu().numpy())
+        assert cut.tobytes() == whole.tobytes(), stage_rows
+    # a chunked table needs an ascending offset table
+    seg = h["seg_off"].copy()
+    seg[5], seg[6] = seg[6], seg[5]
+    if seg[5] != seg[6]:
+        with pytest.raises(N.BluError):
+            engine.run_consensus_host(t, seg, h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], "relaxed")
+    monkeypatch.delenv("BLU_STAGE_ROWS")
