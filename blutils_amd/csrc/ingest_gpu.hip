@@ -53,7 +53,12 @@ struct Slot {            // 32 bytes
 
 struct DevTaxidMap { const TaxidMap::E* tab; uint64_t mask; };
 
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("GPU ingest: %s failed: %s", #x, hipGetErrorString(e_)); rc = BLU_ERR_HIP; goto done; } } while (0)
+// out of device memory is not an error of the call: the CPU parser takes the file (oom_fallback is set by the callers
+// that have one)
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+        if (e_ == hipErrorOutOfMemory && oom_fallback) { (void)hipGetLastError(); if (oom_why) *oom_why = "not enough free device memory"; rc = BLU_INGEST_FALLBACK; } \
+        else { set_error("GPU ingest: %s failed: %s", #x, hipGetErrorString(e_)); rc = BLU_ERR_HIP; } \
+        goto done; } } while (0)
 
 // ---- 1. line index ---------------------------------------------------------------------------------------
 constexpr int TILE_THREADS = 256;
@@ -349,6 +354,8 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int device, HitTable& ht, std::string* why) {
     int rc = BLU_OK;
+    const bool oom_fallback = true;
+    std::string* const oom_why = why;
     const bool trace = getenv("BLU_INGEST_TRACE") != nullptr;
     double tp = now_s();
     auto lap = [&](const char* what) {
@@ -364,7 +371,7 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
     if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return BLU_ERR_NO_DEVICE; }
     {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)size * 2.2 + (1ull << 30) > (double)free_b)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)size * 2.6 + (1ull << 30) > (double)free_b)
             return fallback("a file too large for this device's free memory");
     }
 
@@ -680,6 +687,8 @@ DeviceHits::~DeviceHits() {
 
 int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_t* fwd, uint64_t n_tax, int strategy, blu_result* out) {
     int rc = BLU_OK;
+    const bool oom_fallback = false;
+    std::string* const oom_why = nullptr;
     uint32_t *d_fwd = nullptr, *d_milli = nullptr, *d_flag = nullptr;
     blu_result* d_out = nullptr;
     uint32_t inexact = 0;

@@ -979,12 +979,14 @@ int blu_build_consensus_identities_cfg(const char* blast_output_file, const char
     std::vector<uint32_t> fwd(std::max<size_t>(db.taxid.size(), 1));
     blu_taxonomy_row_map(tax, fwd.data(), nullptr);
     std::vector<blu_result> recs(ht.query_names.size());
+    bool done_on_device = false;
     if (ht.dev && !recs.empty()) {
-        // the GPU ingest left the grouped columns on the device: the engine reads them in place
-        rc = device_run_consensus(tax, *ht.dev, fwd.data(), db.taxid.size(), params->strategy, recs.data());   // mod.rs:104-128
-        ht.dev.reset();
-        if (rc != BLU_OK) { blu_taxonomy_destroy(tax); return rc; }
-    } else {
+        // the GPU ingest left the grouped columns on the device: the engine reads them in place (if that fails — e.g. no
+        // room for the work buffers — the host copies of the same columns go through the staging path below)
+        done_on_device = device_run_consensus(tax, *ht.dev, fwd.data(), db.taxid.size(), params->strategy, recs.data()) == BLU_OK;   // mod.rs:104-128
+    }
+    ht.dev.reset();
+    if (!done_on_device) {
         std::vector<uint32_t> eng_rows(ht.tax_desc_row.size());
         for (size_t i = 0; i < eng_rows.size(); ++i)
             eng_rows[i] = ht.tax_desc_row[i] == BLU_UNMATCHED_TAXID ? BLU_UNMATCHED_TAXID : fwd[ht.tax_desc_row[i]];
