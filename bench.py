@@ -63,7 +63,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("BLU_BENCH_FORCE_DIST") == "1"   # (the override lets a 1-GPU box rehearse the RCCL path)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
