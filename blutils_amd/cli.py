@@ -126,17 +126,17 @@ def main(argv=None) -> int:
         raise SystemExit("Custom taxon values are required when the custom taxon option is selected.")
     to_file = args.blutils_out_file is not None
     fmt = args.out_format if (to_file or args.out_format != "json") else "json-compact"
-    text, _ = pipeline.build_consensus_identities(args.blast_out, args.tax_file, args.taxon, args.strategy,
-                                                  args.use_taxid, custom, headers=None, out_format=fmt,
-                                                  device=args.device, parse=False)
     if to_file:
         path = os.path.splitext(args.blutils_out_file)[0] + "." + args.out_format      # PathBuf::set_extension
         parent = os.path.dirname(path)
         if parent and not os.path.exists(parent):
             os.makedirs(parent)
-        with open(path, "w") as f:
-            f.write(text)
+        pipeline.build_consensus_identities(args.blast_out, args.tax_file, args.taxon, args.strategy, args.use_taxid, custom,
+                                            headers=None, out_format=fmt, device=args.device, parse=False, out_path=path)
     else:
+        text, _ = pipeline.build_consensus_identities(args.blast_out, args.tax_file, args.taxon, args.strategy,
+                                                      args.use_taxid, custom, headers=None, out_format=fmt,
+                                                      device=args.device, parse=False)
         sys.stdout.write(text)
     return 0
 

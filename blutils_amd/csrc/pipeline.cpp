@@ -941,13 +941,10 @@ int blu_build_consensus_identities(const char* blast_output_file, const char* co
                                               out_text, out_len, stats);
 }
 
-int blu_build_consensus_identities_cfg(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
-                                       const char* taxonomies_file, const blu_pipeline_params* params,
-                                       const char* run_id_text, const char* config_text, char** out_text, size_t* out_len,
-                                       blu_pipeline_stats* stats) {
-    if (!blast_output_file || !taxonomies_file || !params || !out_text) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
-    *out_text = nullptr;
-    if (out_len) *out_len = 0;
+static int build_document(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
+                          const char* taxonomies_file, const blu_pipeline_params* params, const char* run_id_text,
+                          const char* config_text, std::string* document, blu_pipeline_stats* stats) {
+    if (!blast_output_file || !taxonomies_file || !params || !document) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
     blu_pipeline_stats st{};
     double t0 = now_s();
     Db db;
@@ -1105,13 +1102,43 @@ int blu_build_consensus_identities_cfg(const char* blast_output_file, const char
     else if (doc) { o += "],\"config\":"; o += cfg.empty() ? "null" : cfg; o.push_back('}'); }
     st.t_render_s = now_s() - t0;
     blu_taxonomy_destroy(tax);
+    document->swap(o);
+    if (stats) *stats = st;
+    return BLU_OK;
+}
+
+int blu_build_consensus_identities_cfg(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
+                                       const char* taxonomies_file, const blu_pipeline_params* params,
+                                       const char* run_id_text, const char* config_text, char** out_text, size_t* out_len,
+                                       blu_pipeline_stats* stats) {
+    if (!out_text) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    *out_text = nullptr;
+    if (out_len) *out_len = 0;
+    std::string o;
+    const int rc = build_document(blast_output_file, headers, n_headers, taxonomies_file, params, run_id_text, config_text, &o, stats);
+    if (rc != BLU_OK) return rc;
     char* buf = (char*)malloc(o.size() + 1);
     if (!buf) { set_error("out of memory"); return BLU_ERR_ALLOC; }
     memcpy(buf, o.data(), o.size());
     buf[o.size()] = 0;
     *out_text = buf;
     if (out_len) *out_len = o.size();
-    if (stats) *stats = st;
+    return BLU_OK;
+}
+
+int blu_build_consensus_identities_to_file(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
+                                           const char* taxonomies_file, const blu_pipeline_params* params,
+                                           const char* run_id_text, const char* config_text, const char* out_path,
+                                           blu_pipeline_stats* stats) {
+    if (!out_path) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    std::string o;
+    const int rc = build_document(blast_output_file, headers, n_headers, taxonomies_file, params, run_id_text, config_text, &o, stats);
+    if (rc != BLU_OK) return rc;
+    // write_blutils_output.rs:57-63: an existing file is replaced
+    FILE* fp = fopen(out_path, "wb");
+    if (!fp) { set_error("cannot write %s", out_path); return BLU_ERR_IO; }
+    const bool ok = (o.empty() || fwrite(o.data(), o.size(), 1, fp) == 1);
+    if (fclose(fp) != 0 || !ok) { set_error("cannot write %s", out_path); return BLU_ERR_IO; }
     return BLU_OK;
 }
 

@@ -81,8 +81,9 @@ def build_consensus_identities(blast_output: str, taxonomies_file: str, taxon: s
                                strategy: str = "relaxed", use_taxid: Optional[bool] = None,
                                custom_taxon_values: Optional[dict] = None, headers: Optional[Sequence[str]] = None,
                                out_format: str = "json", device: int = 0, lenient: bool = False, parse: bool = True,
-                               config=None):
-    """Returns (results, stats).  results: the parsed `results` list (json) / list of records (jsonl), sorted by
+                               config=None, out_path: Optional[str] = None):
+    """Returns (results, stats).  With out_path the document is written there by the library (no copy through Python) and
+    (None, stats) is returned.  results: the parsed `results` list (json) / list of records (jsonl), sorted by
     query, or the raw text when parse=False.  config: Some(BlastBuilder) of the run-with-consensus path
     (blutils_amd.blast.BlastBuilder): its run id goes on every result and it is written as the document's config."""
     L = _bind()
@@ -112,6 +113,16 @@ def build_consensus_identities(blast_output: str, taxonomies_file: str, taxon: s
                                                      C.POINTER(PipelineStats)]
     run_id = str(config.run_id).encode() if config is not None else None
     cfg_text = config.render(out_format).encode() if config is not None else None
+    if out_path is not None:
+        L.blu_build_consensus_identities_to_file.restype = C.c_int
+        L.blu_build_consensus_identities_to_file.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_char_p, C.POINTER(PipelineParams),
+                                                             C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(PipelineStats)]
+        rc = L.blu_build_consensus_identities_to_file(blast_output.encode(), C.cast(hdr_arr, C.c_void_p) if hdr_arr else None, n_hdr,
+                                                      taxonomies_file.encode(), C.byref(p), run_id, cfg_text, out_path.encode(),
+                                                      C.byref(st))
+        if rc != N.BLU_OK:
+            raise N.BluError(rc, "blu_build_consensus_identities_to_file")
+        return None, {f: getattr(st, f) for f, _ in PipelineStats._fields_}
     rc = L.blu_build_consensus_identities_cfg(blast_output.encode(), C.cast(hdr_arr, C.c_void_p) if hdr_arr else None, n_hdr,
                                               taxonomies_file.encode(), C.byref(p), run_id, cfg_text, C.byref(text),
                                               C.byref(n), C.byref(st))

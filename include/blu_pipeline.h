@@ -70,6 +70,12 @@ int blu_build_consensus_identities_cfg(const char* blast_output_file, const char
                                        const char* taxonomies_file, const blu_pipeline_params* params,
                                        const char* run_id_text, const char* config_text, char** out_text, size_t* out_len,
                                        blu_pipeline_stats* stats);
+/* The same, with the document written straight to `out_path` (no copy through the caller): what the CLI does with
+ * --blutils-out-file. */
+int blu_build_consensus_identities_to_file(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
+                                           const char* taxonomies_file, const blu_pipeline_params* params,
+                                           const char* run_id_text, const char* config_text, const char* out_path,
+                                           blu_pipeline_stats* stats);
 void blu_free_text(char* text);
 
 /* The text-ingest half alone (no GPU): DB JSON + outfmt-6 TSV -> SoA columns, as blu_build_consensus_identities does it.

@@ -89,9 +89,11 @@ def main():
               f"{size / st['t_load_hits_s'] / 1e9:.2f} GB/s of text, same columns   [{phases}]")
     if args.pipeline:
         t0 = time.time()
-        text, st = pipeline.build_consensus_identities(bt, cache, "bacteria", "relaxed", out_format="jsonl", lenient=True, parse=False)
+        outp = os.path.join(args.dir, "consensus.jsonl")
+        _, st = pipeline.build_consensus_identities(bt, cache, "bacteria", "relaxed", out_format="jsonl", lenient=True, parse=False,
+                                                    out_path=outp)
         wall = time.time() - t0
-        print(f"pipeline: {wall:.2f} s wall for {st['n_queries']} queries / {st['n_hits']} rows -> {len(text) / 1e6:.0f} MB of JSONL "
+        print(f"pipeline: {wall:.2f} s wall for {st['n_queries']} queries / {st['n_hits']} rows -> {os.path.getsize(outp) / 1e6:.0f} MB of JSONL "
               f"({st['n_queries'] / wall / 1e6:.3f} Mq/s end to end): db {st['t_load_db_s']:.3f} s, ingest {st['t_load_hits_s']:.3f} s, "
               f"engine incl. taxonomy build + PCIe staging {st['t_engine_s']:.3f} s, render {st['t_render_s']:.3f} s")
 
