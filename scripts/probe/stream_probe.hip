@@ -21,3 +21,32 @@ extern "C" int probe_read(const void* p, uint64_t bytes, void* sink, int grid, v
     hipLaunchKernelGGL(probe_read_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4*)p, bytes / 16, (uint32_t*)sink);
     return (int)hipGetLastError();
 }
+
+// K arrays read in lockstep (every thread takes the same index from each): does the number of concurrent streams cost
+// anything by itself?  (the stream kernel reads five columns at one index)
+template <int K>
+__global__ __launch_bounds__(256) void probe_read_k_kernel(const u32x4* const* __restrict__ ps, uint64_t n16, uint32_t* __restrict__ sink) {
+    const u32x4* p[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) p[k] = ps[k];
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i < n16; i += stride) {
+        u32x4 v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = p[k][i];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
+extern "C" int probe_read_k(const void* const* ptrs_dev, int k, uint64_t bytes_each, void* sink, int grid, void* stream) {
+    const u32x4* const* ps = (const u32x4* const*)ptrs_dev;
+    if (k == 1) hipLaunchKernelGGL(probe_read_k_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ps, bytes_each / 16, (uint32_t*)sink);
+    else if (k == 2) hipLaunchKernelGGL(probe_read_k_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ps, bytes_each / 16, (uint32_t*)sink);
+    else if (k == 5) hipLaunchKernelGGL(probe_read_k_kernel<5>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ps, bytes_each / 16, (uint32_t*)sink);
+    else return -1;
+    return (int)hipGetLastError();
+}
