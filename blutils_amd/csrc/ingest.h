@@ -5,12 +5,29 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <utility>
 #include <string>
 #include <vector>
 
 #include "blu_consensus.h"
 
 namespace blu {
+
+// std::vector whose resize() leaves trivially-constructible elements uninitialised: the columns are filled right
+// after by parallel writers (scatter threads, device-to-host copies), and a serial zero-fill of GBs of fresh pages
+// would cost more than the fill itself.
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+        else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using Column = std::vector<T, NoInitAlloc<T>>;
 
 // taxid -> row of the taxonomy table; open addressing, 16-byte entries (one cache line touched per lookup: the join
 // runs once per hit row).  First insertion wins for a duplicated taxid.
@@ -65,10 +82,10 @@ struct DeviceHits {
 // What the ingest hands to the engine and the renderer (a2 + a4 + a5 of SURVEY 8a).
 struct HitTable {
     std::vector<std::string> query_names;        // first-appearance order
-    std::vector<uint64_t> seg_off;
-    std::vector<int32_t> bitscore, align_len;
-    std::vector<uint32_t> tax_desc_row, acc_rank;   // acc_rank: rank of the accession in byte order = index into `accessions`
-    std::vector<double> pident;
+    Column<uint64_t> seg_off;
+    Column<int32_t> bitscore, align_len;
+    Column<uint32_t> tax_desc_row, acc_rank;   // acc_rank: rank of the accession in byte order = index into `accessions`
+    Column<double> pident;
     std::vector<std::string> accessions;         // sorted (String::cmp)
     uint64_t unmatched = 0;
     std::unique_ptr<DeviceHits> dev;             // set by the GPU ingest
