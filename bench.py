@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C5"])
     ap.add_argument("--queries", type=int, default=0, help="override the number of queries per GPU")
     ap.add_argument("--taxa", type=int, default=0, help="override the number of taxids")
+    ap.add_argument("--hits-per-query", type=int, default=0, help="override the hits per query of C2 / C3 (blutils' own default is max_target_seqs = 10)")
     ap.add_argument("--strategy", default="relaxed", choices=["relaxed", "cautious"])
     ap.add_argument("--taxon", default="custom", choices=["custom", "bacteria", "fungi", "eukaryotes"])
     ap.add_argument("--cpu-sample", type=int, default=500000, help="queries of the workload timed on the CPU oracle")
@@ -77,6 +78,8 @@ def main():
         cfg["n_queries"] = args.queries
     if args.taxa:
         cfg["n_taxa"] = args.taxa
+    if args.hits_per_query and cfg["zipf"] is None:
+        cfg["hits_per_query"] = args.hits_per_query
     if args.scaling == "strong" and world > 1:
         cfg["n_queries"] = (cfg["n_queries"] + world - 1) // world      # per-GPU query slice of one fixed table
     seed = synth.SEEDS[args.config]

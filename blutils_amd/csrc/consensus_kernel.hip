@@ -33,6 +33,7 @@
 
 #include <climits>
 #include <cstdint>
+#include <type_traits>
 
 #include "blu_internal.h"
 
@@ -331,32 +332,34 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             in_span = my_off >= task_start && (my_end - task_start) <= TASK_SPAN;
             L.seg[lane] = make_uint2((uint32_t)(my_off - task_start), (nrows <= WAVE && in_span) ? (uint32_t)nrows : 0u);
         }
-        // ---------------- phase 1: 4 queries per step, 16 lanes per query, 4 consecutive rows per lane ----------------
-        const uint32_t grp = (uint32_t)lane >> 4, sub4 = ((uint32_t)lane & 15u) * 4u;
+        // ---------------- phase 1: LPQ lanes per query, 4 consecutive rows per lane, 64 / LPQ queries per step ----------------
+        // LPQ is chosen per task from its longest segment: 4 lanes (<= 16 rows: blutils' own default is
+        // max_target_seqs = 10), 8 lanes (<= 32 rows) or 16 lanes (<= 64 rows), so that short segments do not leave
+        // three quarters of the lanes without a row to load.
         struct StepRegs { u32x4 vbs, vtax, vp01, vp23, valn, vacc; int left; uint32_t qi; };
-        // the loads of one step (4 queries); lanes past the end of the segment issue nothing: their registers stay
-        // undefined and are masked by `left`.  No VALU write touches a register with a load in flight, so nothing
-        // waits in front of the issue.
+        auto phase1 = [&](auto lpq_tag) {
+        constexpr uint32_t LPQ = decltype(lpq_tag)::value;
+        constexpr uint32_t QPS = WAVE / LPQ;                      // queries per step
+        const uint32_t grp = (uint32_t)lane / LPQ, sub4 = ((uint32_t)lane % LPQ) * 4u, row16 = (uint32_t)lane >> 4;
+        // the loads of one step; lanes past the end of the segment get an offset the descriptor's range check
+        // rejects: no memory access, no branch around the loads (so the wait counts below are exact).  No VALU write
+        // touches a register with a load in flight, so nothing waits in front of the issue.
         auto issue = [&](uint32_t qb, StepRegs& R) {
             R.qi = qb + grp;                                     // this lane's query (>= nq: empty slot of the table)
             const uint2 sg = L.seg[R.qi];
             R.left = (int)sg.y - (int)sub4;                      // rows of the segment from this lane's first row on
-            // lanes past the end of the segment get an offset the descriptor's range check rejects: no memory
-            // access, no branch around the loads (so the wait counts below are exact)
             const uint32_t voff = R.left > 0 ? (sg.x + sub4) * 4u : 0xFFFFFFF0u;
-            {
-                R.vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
-                R.vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, voff, 0, STREAM_AUX);
-                if (PID32) {
-                    R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff, 0, STREAM_AUX);   // four milli-percent values
-                    R.vp23 = R.vp01;
-                } else {
-                    R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u, 0, STREAM_AUX);
-                    R.vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u + 16u, 0, STREAM_AUX);
-                }
-                R.valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, voff, 0, STREAM_AUX);
-                R.vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, voff, 0, STREAM_AUX);
+            R.vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
+            R.vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, voff, 0, STREAM_AUX);
+            if (PID32) {
+                R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff, 0, STREAM_AUX);   // four milli-percent values
+                R.vp23 = R.vp01;
+            } else {
+                R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u, 0, STREAM_AUX);
+                R.vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u + 16u, 0, STREAM_AUX);
             }
+            R.valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, voff, 0, STREAM_AUX);
+            R.vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, voff, 0, STREAM_AUX);
         };
         auto process = [&](const StepRegs& R) {
             const int left = R.left;
@@ -365,7 +368,12 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             const int b0 = left > 0 ? (int)vbs.x : INT_MIN, b1 = left > 1 ? (int)vbs.y : INT_MIN;
             const int b2 = left > 2 ? (int)vbs.z : INT_MIN, b3 = left > 3 ? (int)vbs.w : INT_MIN;
             int M = imax(imax(b0, b1), imax(b2, b3));
-            ROW_REDUCE(M, imax)                                   // 16-lane rows: M = the query's top bit-score
+            // M = the query's top bit-score: reduction over its LPQ lanes (quad_perm swaps, then half-row / row mirrors:
+            // after the quad steps the lanes of a quad agree, so a mirror pairs every quad with its partner)
+            M = imax(M, dpp<0xB1>(M));
+            M = imax(M, dpp<0x4E>(M));
+            if (LPQ >= 8) M = imax(M, dpp<0x141>(M));             // row_half_mirror
+            if (LPQ >= 16) M = imax(M, dpp<0x140>(M));            // row_mirror
             const bool t0 = left > 0 && b0 == M, t1 = left > 1 && b1 == M, t2 = left > 2 && b2 == M, t3 = left > 3 && b3 == M;
             const uint32_t c = (uint32_t)t0 + (uint32_t)t1 + (uint32_t)t2 + (uint32_t)t3;
             uint32_t incl = c;                                    // inclusive prefix of the top-row counts inside the 16-lane row
@@ -375,12 +383,20 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             incl += (uint32_t)dpp<0x118>((int)incl);
             const uint32_t k0 = (uint32_t)rl((int)incl, 15), k1 = (uint32_t)rl((int)incl, 31);
             const uint32_t k2 = (uint32_t)rl((int)incl, 47), k3 = (uint32_t)rl((int)incl, 63);
-            const bool fits = fill + k0 + k1 + k2 + k3 <= LIST_CAP;   // else: the four queries go to the worklist
+            const bool fits = fill + k0 + k1 + k2 + k3 <= LIST_CAP;   // else: the queries of this step go to the worklist
             const uint32_t p1 = fill + k0, p2 = p1 + k1, p3 = p2 + k2;
-            const uint32_t gbase = grp == 0 ? fill : (grp == 1 ? p1 : (grp == 2 ? p2 : p3));
-            const uint32_t gk = grp == 0 ? k0 : (grp == 1 ? k1 : (grp == 2 ? k2 : k3));
-            if (((uint32_t)lane & 15u) == 0) L.meta[qi] = fits ? (gbase | (gk << 16)) : META_SLOW;
-            uint32_t idx = gbase + incl - c;                      // list slot of this lane's first top row (file order)
+            const uint32_t rbase = row16 == 0 ? fill : (row16 == 1 ? p1 : (row16 == 2 ? p2 : p3));   // list slot where this 16-lane row starts
+            uint32_t gk;                                          // top rows of this lane's query
+            if (LPQ == 16) gk = row16 == 0 ? k0 : (row16 == 1 ? k1 : (row16 == 2 ? k2 : k3));
+            else {
+                gk = c;
+                gk += (uint32_t)dpp<0xB1>((int)gk);
+                gk += (uint32_t)dpp<0x4E>((int)gk);
+                if (LPQ >= 8) gk += (uint32_t)dpp<0x141>((int)gk);
+            }
+            const uint32_t idx0 = rbase + incl - c;               // list slot of this lane's first top row (file order)
+            if (sub4 == 0) L.meta[qi] = fits ? (idx0 | (gk << 16)) : META_SLOW;   // first lane of the query: its exclusive prefix
+            uint32_t idx = idx0;
             const bool tt[4] = {t0, t1, t2, t3};
             const uint32_t xt[4] = {vtax.x, vtax.y, vtax.z, vtax.w}, xa[4] = {valn.x, valn.y, valn.z, valn.w};
             const uint32_t xc[4] = {vacc.x, vacc.y, vacc.z, vacc.w};
@@ -403,12 +419,12 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             }
             if (fits) fill = p3 + k3;
         };
-        // BLU_STEP_SETS steps (4 queries each) have their loads issued together before the first one is processed:
-        // the wave keeps SETS x 5 KiB in flight instead of 5 KiB (its time is a chain of load latencies).
-        for (uint32_t qb = 0; qb < nq; qb += 4 * BLU_STEP_SETS) {
+        // BLU_STEP_SETS steps have their loads issued together before the first one is processed: the wave keeps
+        // SETS x 5 KiB in flight instead of 5 KiB
+        for (uint32_t qb = 0; qb < nq; qb += QPS * BLU_STEP_SETS) {
             StepRegs R[BLU_STEP_SETS];
 #pragma unroll
-            for (int u = 0; u < BLU_STEP_SETS; ++u) issue(qb + 4 * u, R[u]);
+            for (int u = 0; u < BLU_STEP_SETS; ++u) issue(qb + QPS * u, R[u]);
 #pragma unroll
             for (int u = 0; u < BLU_STEP_SETS; ++u) {
                 // every loaded register is read here on every path (otherwise hipcc parks a vmcnt(0) at the loop head)
@@ -417,6 +433,13 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 process(R[u]);
 #endif
             }
+        }
+        };
+        {
+            const uint32_t longest = wave_max_u32(L.seg[lane].y);   // rows of the task's longest in-task segment
+            if (longest <= 16u) phase1(std::integral_constant<uint32_t, 4>());
+            else if (longest <= 32u) phase1(std::integral_constant<uint32_t, 8>());
+            else phase1(std::integral_constant<uint32_t, 16>());
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
