@@ -432,3 +432,23 @@ def test_host_table_staged_in_chunks(monkeypatch):
         with pytest.raises(N.BluError):
             engine.run_consensus_host(t, seg, h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], "relaxed")
     monkeypatch.delenv("BLU_STAGE_ROWS")
+
+
+@pytest.mark.parametrize("hits", [4, 16, 17, 32, 33])
+def test_lanes_per_query_paths(hits):
+    """The stream kernel gives a query 4, 8 or 16 lanes depending on the task's longest segment (<= 16 / 32 / 64 rows):
+    uniform tables on both sides of each boundary, and one ragged table mixing all three, against the oracle."""
+    tax = synth.make_taxonomy(4000, synth.SEEDS["C2"])
+    t = _engine_tax(tax, "custom", H.CUSTOM_16S)
+    h = synth.make_hits(tax, 3000, 100 + hits, hits, p_unmatched=0.003).numpy()
+    for strategy in ("relaxed", "cautious"):
+        _assert_records_equal(_run_host(t, h, strategy), H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S))
+    # ragged: runs of 64 queries each capped at 16 / 32 / 64 rows, carved out of a 64-hit table
+    base = synth.make_hits(tax, 64 * 30, 200 + hits, 64).numpy()
+    rng = np.random.default_rng(hits)
+    caps = np.repeat(rng.choice([16, 32, 64], 30), 64)
+    lens = np.minimum(rng.integers(1, 65, 64 * 30), caps)
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    take = np.concatenate([np.arange(l) + 64 * i for i, l in enumerate(lens)])
+    ragged = {k: (base[k][take] if k != "seg_off" else seg) for k in base}
+    _assert_records_equal(_run_host(t, ragged, "relaxed"), H.columnar(tax, ragged, "custom", "relaxed", H.CUSTOM_16S))
