@@ -353,8 +353,31 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 }  // namespace
 
+// Device allocations of one ingest: everything still registered is freed when the arena goes out of scope, whichever
+// way the function is left.
+struct DeviceArena {
+    std::vector<void*> ptrs;
+    hipError_t alloc(void** p, size_t bytes) {
+        const hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+    void free(void* p) {
+        auto it = std::find(ptrs.begin(), ptrs.end(), p);
+        if (it == ptrs.end()) return;
+        (void)hipFree(p);
+        ptrs.erase(it);
+    }
+    void release(void* p) {   // ownership moves elsewhere
+        auto it = std::find(ptrs.begin(), ptrs.end(), p);
+        if (it != ptrs.end()) ptrs.erase(it);
+    }
+    ~DeviceArena() { for (void* p : ptrs) (void)hipFree(p); }
+};
+
 int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int device, HitTable& ht, std::string* why) {
     int rc = BLU_OK;
+    DeviceArena mem;
     const bool oom_fallback = true;
     std::string* const oom_why = why;
     const bool trace = getenv("BLU_INGEST_TRACE") != nullptr;
@@ -394,22 +417,22 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
     uint64_t n_tiles = (size + TILE_BYTES - 1) / TILE_BYTES;
     auto need_tmp = [&](size_t bytes) -> hipError_t {
         if (bytes <= tmp_bytes) return hipSuccess;
-        if (d_tmp) (void)hipFree(d_tmp);
+        if (d_tmp) mem.free(d_tmp);
         d_tmp = nullptr; tmp_bytes = 0;
-        hipError_t e = hipMalloc(&d_tmp, bytes);
+        hipError_t e = mem.alloc(&d_tmp, bytes);
         if (e == hipSuccess) tmp_bytes = bytes;
         return e;
     };
     auto grid = [](uint64_t n, uint32_t b = 256) { return dim3((unsigned)((n + b - 1) / b)); };
 
     // ---- upload + line index
-    HIPCHK(hipMalloc((void**)&d_text, size + 64));
+    HIPCHK(mem.alloc((void**)&d_text, size + 64));
     HIPCHK(hipMemset(d_text + (size & ~15ull), 0, 64 + (size & 15)));
     HIPCHK(hipMemcpy(d_text, text, size, hipMemcpyHostToDevice));
     lap("upload text");
-    HIPCHK(hipMalloc((void**)&d_tile, (n_tiles + 1) * 4));
-    HIPCHK(hipMalloc((void**)&d_tile_base, (n_tiles + 1) * 4));
-    HIPCHK(hipMalloc((void**)&d_flags, 64));
+    HIPCHK(mem.alloc((void**)&d_tile, (n_tiles + 1) * 4));
+    HIPCHK(mem.alloc((void**)&d_tile_base, (n_tiles + 1) * 4));
+    HIPCHK(mem.alloc((void**)&d_flags, 64));
     HIPCHK(hipMemset(d_flags, 0, 64));
     d_counter = d_flags + 4;                                         // {flags, -, -, -, counter, -, big counters at +8}
     d_big = reinterpret_cast<unsigned long long*>(d_flags + 8);      // [0] unmatched rows, [1] run heads
@@ -429,7 +452,7 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         if (rows64 >= 0x7FFFFFF0ull) { rc = fallback("2^31 rows or more"); goto done; }
         n_rows = (uint32_t)rows64;
         if (n_rows == 0) { rc = fallback("no rows"); goto done; }
-        HIPCHK(hipMalloc((void**)&d_line, ((size_t)n_rows + 2) * 8));
+        HIPCHK(mem.alloc((void**)&d_line, ((size_t)n_rows + 2) * 8));
         HIPCHK(hipMemset(d_line, 0, 8));
         hipLaunchKernelGGL(write_line_starts, grid(n_tiles, 1), dim3(TILE_THREADS), 0, 0, (const uint4*)d_text, (uint64_t)size, d_tile_base, d_line);
         if (open_tail) { const uint64_t end = size + 1; HIPCHK(hipMemcpy(d_line + n_rows, &end, 8, hipMemcpyHostToDevice)); }
@@ -437,12 +460,12 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
     lap("line index");
 
     // ---- parse
-    HIPCHK(hipMalloc((void**)&d_taxmap, row_of.tab.size() * sizeof(TaxidMap::E)));
+    HIPCHK(mem.alloc((void**)&d_taxmap, row_of.tab.size() * sizeof(TaxidMap::E)));
     HIPCHK(hipMemcpy(d_taxmap, row_of.tab.data(), row_of.tab.size() * sizeof(TaxidMap::E), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&d_qh, (size_t)n_rows * 8)); HIPCHK(hipMalloc((void**)&d_ah, (size_t)n_rows * 8));
-    HIPCHK(hipMalloc((void**)&d_qpos, (size_t)n_rows * 8)); HIPCHK(hipMalloc((void**)&d_apos, (size_t)n_rows * 8));
-    HIPCHK(hipMalloc((void**)&d_tax, (size_t)n_rows * 4)); HIPCHK(hipMalloc((void**)&d_pid, (size_t)n_rows * 8));
-    HIPCHK(hipMalloc((void**)&d_aln, (size_t)n_rows * 4)); HIPCHK(hipMalloc((void**)&d_bs, (size_t)n_rows * 4));
+    HIPCHK(mem.alloc((void**)&d_qh, (size_t)n_rows * 8)); HIPCHK(mem.alloc((void**)&d_ah, (size_t)n_rows * 8));
+    HIPCHK(mem.alloc((void**)&d_qpos, (size_t)n_rows * 8)); HIPCHK(mem.alloc((void**)&d_apos, (size_t)n_rows * 8));
+    HIPCHK(mem.alloc((void**)&d_tax, (size_t)n_rows * 4)); HIPCHK(mem.alloc((void**)&d_pid, (size_t)n_rows * 8));
+    HIPCHK(mem.alloc((void**)&d_aln, (size_t)n_rows * 4)); HIPCHK(mem.alloc((void**)&d_bs, (size_t)n_rows * 4));
     {
         RowOut o{d_qh, d_ah, d_qpos, d_apos, d_tax, d_pid, d_aln, d_bs};
         DevTaxidMap tm{d_taxmap, row_of.tab.size() - 1};
@@ -458,15 +481,15 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         unsigned long long runs = 0;
         HIPCHK(hipMemcpy(&runs, d_big + 1, 8, hipMemcpyDeviceToHost));
         const uint64_t cap = pow2_at_least(runs * 2 + 16);
-        HIPCHK(hipMalloc((void**)&d_qtab, cap * sizeof(Slot)));
+        HIPCHK(mem.alloc((void**)&d_qtab, cap * sizeof(Slot)));
         hipLaunchKernelGGL(dict_init, grid(cap), dim3(256), 0, 0, d_qtab, cap);   // empty slots, first_row = all ones for atomicMin
         HIPCHK(hipMemset(d_counter, 0, 4));
         hipLaunchKernelGGL(dict_insert, grid(n_rows), dim3(256), 0, 0, d_qh, n_rows, d_qtab, cap - 1, true, d_counter, d_flags);
         HIPCHK(hipMemcpy(&n_queries, d_counter, 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
         if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
-        HIPCHK(hipMalloc((void**)&d_list_row, (size_t)n_queries * 4)); HIPCHK(hipMalloc((void**)&d_list_slot, (size_t)n_queries * 4));
-        HIPCHK(hipMalloc((void**)&d_list_row2, (size_t)n_queries * 4)); HIPCHK(hipMalloc((void**)&d_list_slot2, (size_t)n_queries * 4));
+        HIPCHK(mem.alloc((void**)&d_list_row, (size_t)n_queries * 4)); HIPCHK(mem.alloc((void**)&d_list_slot, (size_t)n_queries * 4));
+        HIPCHK(mem.alloc((void**)&d_list_row2, (size_t)n_queries * 4)); HIPCHK(mem.alloc((void**)&d_list_slot2, (size_t)n_queries * 4));
         HIPCHK(hipMemset(d_counter, 0, 4));
         hipLaunchKernelGGL(dict_finalize, grid(cap), dim3(256), 0, 0, d_qtab, cap, d_text, d_qpos, d_list_row, d_list_slot, d_counter);
         size_t b = 0;
@@ -474,12 +497,12 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         HIPCHK(need_tmp(b));
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, b, d_list_row, d_list_row2, d_list_slot, d_list_slot2, (int)n_queries));
         hipLaunchKernelGGL(dict_assign_ids, grid(n_queries), dim3(256), 0, 0, d_qtab, d_list_slot2, (const uint32_t*)nullptr, n_queries);
-        HIPCHK(hipMalloc((void**)&d_qid, (size_t)n_rows * 4));
+        HIPCHK(mem.alloc((void**)&d_qid, (size_t)n_rows * 4));
         hipLaunchKernelGGL(dict_lookup, grid(n_rows), dim3(256), 0, 0, d_qh, d_qpos, n_rows, d_qtab, cap - 1, d_text, d_qpos, d_qid, d_flags);
         HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
         if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
         // query names: the text of each query's first row, in id order
-        HIPCHK(hipMalloc((void**)&d_poslist, (size_t)n_queries * 8));
+        HIPCHK(mem.alloc((void**)&d_poslist, (size_t)n_queries * 8));
         hipLaunchKernelGGL(gather_pos, grid(n_queries), dim3(256), 0, 0, d_qpos, d_list_row2, n_queries, d_poslist);
         std::vector<unsigned long long> qp(n_queries);
         HIPCHK(hipMemcpy(qp.data(), d_poslist, (size_t)n_queries * 8, hipMemcpyDeviceToHost));
@@ -497,12 +520,12 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
                 });
             for (auto& th : pool) th.join();
         }
-        (void)hipFree(d_poslist); d_poslist = nullptr;
-        (void)hipFree(d_list_row); (void)hipFree(d_list_slot); (void)hipFree(d_list_row2); (void)hipFree(d_list_slot2);
+        mem.free(d_poslist); d_poslist = nullptr;
+        mem.free(d_list_row); mem.free(d_list_slot); mem.free(d_list_row2); mem.free(d_list_slot2);
         d_list_row = d_list_slot = d_list_row2 = d_list_slot2 = nullptr;
-        (void)hipFree(d_qtab); d_qtab = nullptr;
-        (void)hipFree(d_qh); d_qh = nullptr;
-        (void)hipFree(d_qpos); d_qpos = nullptr;
+        mem.free(d_qtab); d_qtab = nullptr;
+        mem.free(d_qh); d_qh = nullptr;
+        mem.free(d_qpos); d_qpos = nullptr;
     }
     lap("query dictionary");
 
@@ -510,7 +533,7 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
     {
         uint64_t cap = pow2_at_least(std::min<uint64_t>((uint64_t)n_rows * 2 + 16, 1ull << 22));
         for (;;) {
-            HIPCHK(hipMalloc((void**)&d_atab, cap * sizeof(Slot)));
+            HIPCHK(mem.alloc((void**)&d_atab, cap * sizeof(Slot)));
             hipLaunchKernelGGL(dict_init, grid(cap), dim3(256), 0, 0, d_atab, cap);
             HIPCHK(hipMemset(d_counter, 0, 4));
             HIPCHK(hipMemset(d_flags, 0, 4));
@@ -518,16 +541,16 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
             HIPCHK(hipMemcpy(&n_acc, d_counter, 4, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
             if (!(h_flags & FB_TABLE_FULL) && (uint64_t)n_acc * 2 <= cap) break;
-            (void)hipFree(d_atab); d_atab = nullptr;
+            mem.free(d_atab); d_atab = nullptr;
             if (cap >= pow2_at_least((uint64_t)n_rows * 2 + 16)) { rc = fallback(fallback_text(FB_TABLE_FULL)); goto done; }
             cap *= 4;
         }
         lap("  acc: insert");
         HIPCHK(hipMemset(d_flags, 0, 4));
-        HIPCHK(hipMalloc((void**)&d_list_row, (size_t)n_acc * 4)); HIPCHK(hipMalloc((void**)&d_list_slot, (size_t)n_acc * 4));
+        HIPCHK(mem.alloc((void**)&d_list_row, (size_t)n_acc * 4)); HIPCHK(mem.alloc((void**)&d_list_slot, (size_t)n_acc * 4));
         HIPCHK(hipMemset(d_counter, 0, 4));
         hipLaunchKernelGGL(dict_finalize, grid(cap), dim3(256), 0, 0, d_atab, cap, d_text, d_apos, d_list_row, d_list_slot, d_counter);
-        HIPCHK(hipMalloc((void**)&d_poslist, (size_t)n_acc * 8));
+        HIPCHK(mem.alloc((void**)&d_poslist, (size_t)n_acc * 8));
         hipLaunchKernelGGL(gather_pos, grid(n_acc), dim3(256), 0, 0, d_apos, d_list_row, n_acc, d_poslist);
         std::vector<unsigned long long> ap(n_acc);
         HIPCHK(hipMemcpy(ap.data(), d_poslist, (size_t)n_acc * 8, hipMemcpyDeviceToHost));
@@ -538,15 +561,15 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         std::vector<unsigned long long> k0(n_acc), k1(n_acc);
         {
             unsigned long long *d_k0 = nullptr, *d_k1 = nullptr;
-            HIPCHK(hipMalloc((void**)&d_k0, (size_t)n_acc * 8 + 8));
-            hipError_t e2 = hipMalloc((void**)&d_k1, (size_t)n_acc * 8 + 8);
+            HIPCHK(mem.alloc((void**)&d_k0, (size_t)n_acc * 8 + 8));
+            hipError_t e2 = mem.alloc((void**)&d_k1, (size_t)n_acc * 8 + 8);
             if (e2 == hipSuccess) {
                 hipLaunchKernelGGL(gather_key16, grid(n_acc), dim3(256), 0, 0, d_poslist, n_acc, d_text, d_k0, d_k1);
                 e2 = hipMemcpy(k0.data(), d_k0, (size_t)n_acc * 8, hipMemcpyDeviceToHost);
                 if (e2 == hipSuccess) e2 = hipMemcpy(k1.data(), d_k1, (size_t)n_acc * 8, hipMemcpyDeviceToHost);
             }
-            (void)hipFree(d_k0);
-            if (d_k1) (void)hipFree(d_k1);
+            mem.free(d_k0);
+            mem.free(d_k1);
             HIPCHK(e2);
         }
         std::vector<uint32_t> order(n_acc);
@@ -578,17 +601,17 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         ht.accessions.resize(n_acc);
         for (uint32_t r = 0; r < n_acc; ++r) { rank_of[order[r]] = r; ht.accessions[r].assign(view(order[r])); }
         lap("  acc: strings");
-        HIPCHK(hipMalloc((void**)&d_ranks, (size_t)n_acc * 4));
+        HIPCHK(mem.alloc((void**)&d_ranks, (size_t)n_acc * 4));
         HIPCHK(hipMemcpy(d_ranks, rank_of.data(), (size_t)n_acc * 4, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(dict_assign_ids, grid(n_acc), dim3(256), 0, 0, d_atab, d_list_slot, (const uint32_t*)d_ranks, n_acc);
-        HIPCHK(hipMalloc((void**)&d_arank, (size_t)n_rows * 4));
+        HIPCHK(mem.alloc((void**)&d_arank, (size_t)n_rows * 4));
         hipLaunchKernelGGL(dict_lookup, grid(n_rows), dim3(256), 0, 0, d_ah, d_apos, n_rows, d_atab, cap - 1, d_text, d_apos, d_arank, d_flags);
         HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
         if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
-        (void)hipFree(d_atab); d_atab = nullptr;
-        (void)hipFree(d_ah); d_ah = nullptr;
-        (void)hipFree(d_apos); d_apos = nullptr;
-        (void)hipFree(d_text); d_text = nullptr;
+        mem.free(d_atab); d_atab = nullptr;
+        mem.free(d_ah); d_ah = nullptr;
+        mem.free(d_apos); d_apos = nullptr;
+        mem.free(d_text); d_text = nullptr;
     }
     lap("accession dictionary");
 
@@ -599,8 +622,8 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         uint32_t unsorted = 0;
         HIPCHK(hipMemcpy(&unsorted, d_counter, 4, hipMemcpyDeviceToHost));
         if (unsorted) {
-            HIPCHK(hipMalloc((void**)&d_perm, (size_t)n_rows * 4)); HIPCHK(hipMalloc((void**)&d_perm2, (size_t)n_rows * 4));
-            HIPCHK(hipMalloc((void**)&d_qid2, (size_t)n_rows * 4));
+            HIPCHK(mem.alloc((void**)&d_perm, (size_t)n_rows * 4)); HIPCHK(mem.alloc((void**)&d_perm2, (size_t)n_rows * 4));
+            HIPCHK(mem.alloc((void**)&d_qid2, (size_t)n_rows * 4));
             hipLaunchKernelGGL(iota_u32, grid(n_rows), dim3(256), 0, 0, d_perm, n_rows);
             int bits = 1;
             while ((1ull << bits) < n_queries) ++bits;
@@ -609,16 +632,16 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
             HIPCHK(need_tmp(b));
             HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, b, d_qid, d_qid2, d_perm, d_perm2, (int)n_rows, 0, bits));   // stable
         }
-        HIPCHK(hipMalloc((void**)&d_seg, ((size_t)n_queries + 1) * 8 * 2));
+        HIPCHK(mem.alloc((void**)&d_seg, ((size_t)n_queries + 1) * 8 * 2));
         HIPCHK(hipMemset(d_seg, 0, ((size_t)n_queries + 1) * 8 * 2));
         hipLaunchKernelGGL(histogram_qid, grid(n_rows), dim3(256), 0, 0, d_qid, n_rows, d_seg);
         size_t b = 0;
         HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_seg, d_seg + n_queries + 1, (int)(n_queries + 1)));
         HIPCHK(need_tmp(b));
         HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, b, d_seg, d_seg + n_queries + 1, (int)(n_queries + 1)));
-        HIPCHK(hipMalloc((void**)&d_bs2, (size_t)n_rows * 4)); HIPCHK(hipMalloc((void**)&d_aln2, (size_t)n_rows * 4));
-        HIPCHK(hipMalloc((void**)&d_tax2, (size_t)n_rows * 4)); HIPCHK(hipMalloc((void**)&d_arank2, (size_t)n_rows * 4));
-        HIPCHK(hipMalloc((void**)&d_pid2, (size_t)n_rows * 8));
+        HIPCHK(mem.alloc((void**)&d_bs2, (size_t)n_rows * 4)); HIPCHK(mem.alloc((void**)&d_aln2, (size_t)n_rows * 4));
+        HIPCHK(mem.alloc((void**)&d_tax2, (size_t)n_rows * 4)); HIPCHK(mem.alloc((void**)&d_arank2, (size_t)n_rows * 4));
+        HIPCHK(mem.alloc((void**)&d_pid2, (size_t)n_rows * 8));
         Cols in{d_bs, d_aln, d_tax, d_arank, d_pid};
         ColsOut out{d_bs2, d_aln2, d_tax2, d_arank2, d_pid2};
         hipLaunchKernelGGL(gather_cols, grid(n_rows), dim3(256), 0, 0, in, out, (const uint32_t*)(unsorted ? d_perm2 : nullptr), n_rows);
@@ -663,16 +686,11 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         ht.dev->device = device; ht.dev->n_hits = n_rows; ht.dev->n_queries = n_queries;
         ht.dev->bitscore = d_bs2; ht.dev->align_len = d_aln2; ht.dev->tax_desc_row = d_tax2; ht.dev->acc_rank = d_arank2; ht.dev->pident = d_pid2;
         ht.dev->seg_off = d_seg + n_queries + 1; ht.dev->seg_block = d_seg;
-        d_bs2 = d_aln2 = nullptr; d_tax2 = d_arank2 = nullptr; d_pid2 = nullptr; d_seg = nullptr;
+        for (void* q : {(void*)d_bs2, (void*)d_aln2, (void*)d_tax2, (void*)d_arank2, (void*)d_pid2, (void*)d_seg}) mem.release(q);
     }
     lap("download columns");
 
 done:
-    for (void* p : {(void*)d_text, (void*)d_tile, (void*)d_tile_base, (void*)d_flags, (void*)d_line, d_tmp, (void*)d_taxmap, (void*)d_qh, (void*)d_ah,
-                    (void*)d_qpos, (void*)d_apos, (void*)d_poslist, (void*)d_tax, (void*)d_qid, (void*)d_arank, (void*)d_list_row, (void*)d_list_slot,
-                    (void*)d_list_row2, (void*)d_list_slot2, (void*)d_perm, (void*)d_perm2, (void*)d_qid2, (void*)d_ranks, (void*)d_pid, (void*)d_pid2,
-                    (void*)d_aln, (void*)d_bs, (void*)d_aln2, (void*)d_bs2, (void*)d_tax2, (void*)d_arank2, (void*)d_qtab, (void*)d_atab, (void*)d_seg})
-        if (p) (void)hipFree(p);
     if (rc != BLU_OK) {
         ht = HitTable();
     }
