@@ -4,9 +4,9 @@
 // find_single_query_consensus.rs:17-173, find_multi_taxa_consensus.rs:22-217,
 // build_blast_consensus_identity.rs:9-105 (restated in SURVEY §3.3).
 //
-// Kernel A  blu_consensus_stream_kernel — the streaming path (segments <= 64 hits).
+// Kernel A  blu_consensus_stream_kernel — the streaming path (segments <= 256 hits).
 //   A wave task is 64 consecutive queries; the waves of a block take consecutive tasks.
-//   phase 1 (lane = 4 consecutive hit rows, 16 lanes per query, 4 queries per step):
+//   phase 1 (lane = 4 consecutive hit rows; 4 .. 64 lanes per query, chosen per task from its longest segment):
 //     16-byte buffer loads of the five SoA columns, M = max bit_score by a 16-lane
 //     DPP row reduction, top rows ranked by a DPP row scan and compacted in file
 //     order into a per-wave LDS list (row id, align_len, accession rank, position,
@@ -19,7 +19,7 @@
 //     node ids; per-level cutoff ids (values in LDS) and rank codes come from the
 //     table row of the lineage's shape; cutoff tests; record.
 //   Records are staged in LDS and leave as one write-through burst per block.
-//   Queries with more than 64 hits, or whose top group does not fit the LDS
+//   Queries with more than 256 hits, or whose top group does not fit the LDS
 //   list, are appended to a worklist.
 // Kernel B  blu_consensus_long_kernel — worklist queries, one wave per query,
 //   chunked passes over the segment (any length), wave-parallel finalisation.
@@ -232,6 +232,7 @@ __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
 static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 
 #define META_SLOW 0x80000000u
+#define MAX_TASK_SEG 256u        // longest segment the stream kernel takes (64 lanes x 4 rows); longer ones go to the worklist
 #ifndef BLOCK_B
 #define BLOCK_B 256
 #endif
@@ -258,7 +259,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct WaveLds {
     Entry list[LIST_CAP];       // top-group rows of the task's queries, file order
     uint32_t meta[WAVE + 4];    // first entry | k << 16, or META_SLOW
-    uint2 seg[WAVE + 4];        // {first row relative to the task's first row, row count (0 if > 64)}
+    uint2 seg[WAVE + 4];        // {first row relative to the task's first row, row count (0 if > MAX_TASK_SEG or outside the span)}
 };
 
 #ifndef BLU_STEP_SETS
@@ -330,12 +331,14 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         {
             const uint64_t nrows = my_end - my_off;
             in_span = my_off >= task_start && (my_end - task_start) <= TASK_SPAN;
-            L.seg[lane] = make_uint2((uint32_t)(my_off - task_start), (nrows <= WAVE && in_span) ? (uint32_t)nrows : 0u);
+            L.seg[lane] = make_uint2((uint32_t)(my_off - task_start), (nrows <= MAX_TASK_SEG && in_span) ? (uint32_t)nrows : 0u);
         }
         // ---------------- phase 1: LPQ lanes per query, 4 consecutive rows per lane, 64 / LPQ queries per step ----------------
         // LPQ is chosen per task from its longest segment: 4 lanes (<= 16 rows: blutils' own default is
-        // max_target_seqs = 10), 8 lanes (<= 32 rows) or 16 lanes (<= 64 rows), so that short segments do not leave
-        // three quarters of the lanes without a row to load.
+        // max_target_seqs = 10), 8 (<= 32), 16 (<= 64), 32 (<= 128) or all 64 lanes (<= 256 rows: BLAST's own default
+        // of 500 target sequences rarely leaves more than that after blutils' identity / coverage filters), so that
+        // short segments do not leave most lanes without a row to load and long ones still share the lane-per-query
+        // finalisation of phase 2.
         struct StepRegs { u32x4 vbs, vtax, vp01, vp23, valn, vacc; int left; uint32_t qi; };
         auto phase1 = [&](auto lpq_tag) {
         constexpr uint32_t LPQ = decltype(lpq_tag)::value;
@@ -374,6 +377,10 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             M = imax(M, dpp<0x4E>(M));
             if (LPQ >= 8) M = imax(M, dpp<0x141>(M));             // row_half_mirror
             if (LPQ >= 16) M = imax(M, dpp<0x140>(M));            // row_mirror
+            if (LPQ >= 32) {                                      // the 16-lane rows agree inside; combine two or all four
+                const int m0 = rl(M, 0), m1 = rl(M, 16), m2 = rl(M, 32), m3 = rl(M, 48);
+                M = LPQ == 64 ? imax(imax(m0, m1), imax(m2, m3)) : (row16 < 2 ? imax(m0, m1) : imax(m2, m3));
+            }
             const bool t0 = left > 0 && b0 == M, t1 = left > 1 && b1 == M, t2 = left > 2 && b2 == M, t3 = left > 3 && b3 == M;
             const uint32_t c = (uint32_t)t0 + (uint32_t)t1 + (uint32_t)t2 + (uint32_t)t3;
             uint32_t incl = c;                                    // inclusive prefix of the top-row counts inside the 16-lane row
@@ -387,7 +394,9 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             const uint32_t p1 = fill + k0, p2 = p1 + k1, p3 = p2 + k2;
             const uint32_t rbase = row16 == 0 ? fill : (row16 == 1 ? p1 : (row16 == 2 ? p2 : p3));   // list slot where this 16-lane row starts
             uint32_t gk;                                          // top rows of this lane's query
-            if (LPQ == 16) gk = row16 == 0 ? k0 : (row16 == 1 ? k1 : (row16 == 2 ? k2 : k3));
+            if (LPQ == 64) gk = k0 + k1 + k2 + k3;
+            else if (LPQ == 32) gk = row16 < 2 ? k0 + k1 : k2 + k3;
+            else if (LPQ == 16) gk = row16 == 0 ? k0 : (row16 == 1 ? k1 : (row16 == 2 ? k2 : k3));
             else {
                 gk = c;
                 gk += (uint32_t)dpp<0xB1>((int)gk);
@@ -439,7 +448,9 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             const uint32_t longest = wave_max_u32(L.seg[lane].y);   // rows of the task's longest in-task segment
             if (longest <= 16u) phase1(std::integral_constant<uint32_t, 4>());
             else if (longest <= 32u) phase1(std::integral_constant<uint32_t, 8>());
-            else phase1(std::integral_constant<uint32_t, 16>());
+            else if (longest <= 64u) phase1(std::integral_constant<uint32_t, 16>());
+            else if (longest <= 128u) phase1(std::integral_constant<uint32_t, 32>());
+            else phase1(std::integral_constant<uint32_t, 64>());
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -477,9 +488,9 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             const uint64_t nrows = my_end - my_off;
             const uint32_t m = L.meta[lane];
             if (nrows == 0) { pack_status(ra, rb, BLU_ST_NO_HITS, 0xFFFFFFFFu); rec_kind = 1; }   // mod.rs:107-113
-            else if (nrows > WAVE || !in_span || (m & META_SLOW)) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
+            else if (nrows > MAX_TASK_SEG || !in_span || (m & META_SLOW)) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
             else {
-                const uint32_t first = m & 0xFFFF, k = (m >> 16) & 0xFF;
+                const uint32_t first = m & 0xFFFF, k = (m >> 16) & 0x1FF;
                 // parse errors first, in file order (find_single_query_consensus.rs:51-64), then NaN pident
                 uint32_t err = 0, err_pos = 0;
                 for (uint32_t e = 0; e < k; ++e) {

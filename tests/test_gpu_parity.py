@@ -434,21 +434,22 @@ def test_host_table_staged_in_chunks(monkeypatch):
     monkeypatch.delenv("BLU_STAGE_ROWS")
 
 
-@pytest.mark.parametrize("hits", [4, 16, 17, 32, 33])
+@pytest.mark.parametrize("hits", [4, 16, 17, 32, 33, 64, 65, 128, 129, 256, 257])
 def test_lanes_per_query_paths(hits):
-    """The stream kernel gives a query 4, 8 or 16 lanes depending on the task's longest segment (<= 16 / 32 / 64 rows):
-    uniform tables on both sides of each boundary, and one ragged table mixing all three, against the oracle."""
+    """The stream kernel gives a query 4, 8, 16, 32 or 64 lanes depending on the task's longest segment (<= 16 / 32 / 64 /
+    128 / 256 rows; longer segments go to the worklist kernel): uniform tables on both sides of each boundary, and one
+    ragged table mixing them, against the oracle."""
     tax = synth.make_taxonomy(4000, synth.SEEDS["C2"])
     t = _engine_tax(tax, "custom", H.CUSTOM_16S)
-    h = synth.make_hits(tax, 3000, 100 + hits, hits, p_unmatched=0.003).numpy()
+    h = synth.make_hits(tax, 3000 if hits <= 64 else 700, 100 + hits, hits, p_unmatched=0.003).numpy()
     for strategy in ("relaxed", "cautious"):
         _assert_records_equal(_run_host(t, h, strategy), H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S))
-    # ragged: runs of 64 queries each capped at 16 / 32 / 64 rows, carved out of a 64-hit table
-    base = synth.make_hits(tax, 64 * 30, 200 + hits, 64).numpy()
+    # ragged: runs of 64 queries each capped at 16 / 32 / 64 / 128 / 256 / 300 rows, carved out of a 300-hit table
+    base = synth.make_hits(tax, 64 * 30, 200 + hits, 300).numpy()
     rng = np.random.default_rng(hits)
-    caps = np.repeat(rng.choice([16, 32, 64], 30), 64)
-    lens = np.minimum(rng.integers(1, 65, 64 * 30), caps)
+    caps = np.repeat(rng.choice([16, 32, 64, 128, 256, 300], 30), 64)
+    lens = np.minimum(rng.integers(1, 301, 64 * 30), caps)
     seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    take = np.concatenate([np.arange(l) + 64 * i for i, l in enumerate(lens)])
+    take = np.concatenate([np.arange(l) + 300 * i for i, l in enumerate(lens)])
     ragged = {k: (base[k][take] if k != "seg_off" else seg) for k in base}
     _assert_records_equal(_run_host(t, ragged, "relaxed"), H.columnar(tax, ragged, "custom", "relaxed", H.CUSTOM_16S))
