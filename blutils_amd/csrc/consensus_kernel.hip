@@ -4,7 +4,7 @@
 // find_single_query_consensus.rs:17-173, find_multi_taxa_consensus.rs:22-217,
 // build_blast_consensus_identity.rs:9-105 (restated in SURVEY §3.3).
 //
-// Kernel A  blu_consensus_stream_kernel — the streaming path (segments <= 256 hits).
+// Kernel A  blu_consensus_stream_kernel — the streaming path (segments <= 512 hits).
 //   A wave task is 64 consecutive queries; the waves of a block take consecutive tasks.
 //   phase 1 (lane = 4 consecutive hit rows; 4 .. 64 lanes per query, chosen per task from its longest segment):
 //     16-byte buffer loads of the five SoA columns, M = max bit_score by a 16-lane
@@ -19,7 +19,7 @@
 //     node ids; per-level cutoff ids (values in LDS) and rank codes come from the
 //     table row of the lineage's shape; cutoff tests; record.
 //   Records are staged in LDS and leave as one write-through burst per block.
-//   Queries with more than 256 hits, or whose top group does not fit the LDS
+//   Queries with more than 512 hits, or whose top group does not fit the LDS
 //   list, are appended to a worklist.
 // Kernel B  blu_consensus_long_kernel — worklist queries, one wave per query,
 //   chunked passes over the segment (any length), wave-parallel finalisation.
@@ -214,7 +214,7 @@ __device__ __forceinline__ uint32_t shared_levels(const TaxDev& t, uint32_t lo, 
 // Kernel A
 // ===============================================================================
 struct Entry {            // one top-group row in LDS, 24 bytes
-    uint32_t id, aln, acc, pq;    // id = engine row id (sorted position | length << BLU_ROW_BITS); pq = position in the segment | query-in-task << 8
+    uint32_t id, aln, acc, pq;    // id = engine row id (sorted position | length << BLU_ROW_BITS); pq = position in the segment
     uint32_t p0, p1;              // pident: f64 bits (lo, hi), or the milli-percent integer in p0
 };
 template <bool PID32> struct PidKey { typedef double type; };
@@ -232,7 +232,8 @@ __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
 static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 
 #define META_SLOW 0x80000000u
-#define MAX_TASK_SEG 256u        // longest segment the stream kernel takes (64 lanes x 4 rows); longer ones go to the worklist
+#define SHORT_SEG 128u           // segments up to here are streamed (4 .. 32 lanes per query); longer ones take the sparse long pass
+#define MAX_TASK_SEG 512u        // longest segment the stream kernel takes (64 lanes x 4 rows, twice); longer ones go to the worklist
 #ifndef BLOCK_B
 #define BLOCK_B 256
 #endif
@@ -340,17 +341,18 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         // short segments do not leave most lanes without a row to load and long ones still share the lane-per-query
         // finalisation of phase 2.
         struct StepRegs { u32x4 vbs, vtax, vp01, vp23, valn, vacc; int left; uint32_t qi; };
-        auto phase1 = [&](auto lpq_tag) {
-        constexpr uint32_t LPQ = decltype(lpq_tag)::value;
-        constexpr uint32_t QPS = WAVE / LPQ;                      // queries per step
-        const uint32_t grp = (uint32_t)lane / LPQ, sub4 = ((uint32_t)lane % LPQ) * 4u, row16 = (uint32_t)lane >> 4;
+        auto phase1 = [&](const auto lpq) {                       // wave-uniform width: a constant for 16 lanes, a variable otherwise
+        const uint32_t LPQ = lpq;
+        const uint32_t QPS = WAVE / LPQ;                          // queries per step
+        const uint32_t grp = (uint32_t)lane / LPQ, sub4 = ((uint32_t)lane & (LPQ - 1u)) * 4u, row16 = (uint32_t)lane >> 4;
         // the loads of one step; lanes past the end of the segment get an offset the descriptor's range check
         // rejects: no memory access, no branch around the loads (so the wait counts below are exact).  No VALU write
         // touches a register with a load in flight, so nothing waits in front of the issue.
         auto issue = [&](uint32_t qb, StepRegs& R) {
             R.qi = qb + grp;                                     // this lane's query (>= nq: empty slot of the table)
             const uint2 sg = L.seg[R.qi];
-            R.left = (int)sg.y - (int)sub4;                      // rows of the segment from this lane's first row on
+            // rows of the segment from this lane's first row on (segments over SHORT_SEG rows belong to the long pass)
+            R.left = (sg.y > SHORT_SEG ? 0 : (int)sg.y) - (int)sub4;
             const uint32_t voff = R.left > 0 ? (sg.x + sub4) * 4u : 0xFFFFFFF0u;
             R.vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
             R.vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, voff, 0, STREAM_AUX);
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 if (fits && tt[r]) {
 #endif
                     Entry e;
-                    e.id = xt[r]; e.aln = xa[r]; e.acc = xc[r]; e.pq = (sub4 + r) | (qi << 8);
+                    e.id = xt[r]; e.aln = xa[r]; e.acc = xc[r]; e.pq = sub4 + r;
                     e.p0 = PID32 ? xm[r] : xlo[r];
                     e.p1 = PID32 ? 0u : xhi[r];
                     L.list[idx] = e;   // the row id carries the lineage length: phase 1 touches no taxonomy table
@@ -444,13 +446,114 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             }
         }
         };
+        // Segments of 129..512 rows: a step holds two 256-row slots — two queries, or the two halves of one query longer
+        // than 256 rows.  The bit-scores of both slots are loaded together; the other four columns are then read only by
+        // the lanes that hold a top row (the rest get an offset the descriptor rejects: no memory access): top rows are
+        // sparse in segments this long, so most of their lines are never fetched.
+        auto phase1_long = [&](uint64_t long_mask) {
+            const uint32_t sub4 = (uint32_t)lane * 4u, row16 = (uint32_t)lane >> 4;
+            while (long_mask) {
+                // next long query; one longer than 256 rows takes both slots (its two halves), otherwise the following
+                // long query — if it fits a slot too — shares the step
+                const uint32_t qi = (uint32_t)__builtin_ctzll(long_mask);
+                long_mask &= long_mask - 1;
+                const bool halves = L.seg[qi].y > 256u;
+                uint32_t q_other = 64u;                           // 64 = none
+                if (!halves && long_mask) {
+                    const uint32_t cand = (uint32_t)__builtin_ctzll(long_mask);
+                    if (L.seg[cand].y <= 256u) { q_other = cand; long_mask &= long_mask - 1; }
+                }
+                u32x4 vb[2];
+                int left[2];
+                uint32_t voff[2], qs[2], ro[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    qs[hf] = (halves || hf == 0) ? qi : q_other;
+                    ro[hf] = halves ? 256u * (uint32_t)hf : 0u;
+                    uint2 sg = L.seg[qs[hf] < 64u ? qs[hf] : 0u];
+                    if (qs[hf] >= 64u) sg.y = 0;
+                    left[hf] = (int)sg.y - (int)ro[hf] - (int)sub4;
+                    voff[hf] = left[hf] > 0 ? (sg.x + ro[hf] + sub4) * 4u : 0xFFFFFFF0u;
+                    vb[hf] = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff[hf], 0, STREAM_AUX);
+                }
+                asm volatile("" ::"v"(vb[0]), "v"(vb[1]));
+                int bs[2][4], m[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const uint32_t v[4] = {vb[hf].x, vb[hf].y, vb[hf].z, vb[hf].w};
+                    m[hf] = INT_MIN;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { bs[hf][r] = left[hf] > r ? (int)v[r] : INT_MIN; m[hf] = imax(m[hf], bs[hf][r]); }
+                }
+                if (halves) { m[0] = imax(m[0], m[1]); m[0] = wave_max_i32(m[0]); m[1] = m[0]; }   // one query: one top bit-score
+                else { m[0] = wave_max_i32(m[0]); m[1] = wave_max_i32(m[1]); }
+                uint32_t c[2], slot[2], tot[2], tmask[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    c[hf] = 0; tmask[hf] = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const bool t = left[hf] > r && bs[hf][r] == m[hf]; tmask[hf] |= (uint32_t)t << r; c[hf] += (uint32_t)t; }
+                    uint32_t in = c[hf];
+                    in += (uint32_t)dpp<0x111>((int)in);
+                    in += (uint32_t)dpp<0x112>((int)in);
+                    in += (uint32_t)dpp<0x114>((int)in);
+                    in += (uint32_t)dpp<0x118>((int)in);
+                    const uint32_t k0 = (uint32_t)rl((int)in, 15), k1 = (uint32_t)rl((int)in, 31), k2 = (uint32_t)rl((int)in, 47), k3 = (uint32_t)rl((int)in, 63);
+                    tot[hf] = k0 + k1 + k2 + k3;
+                    slot[hf] = (row16 == 0 ? 0u : (row16 == 1 ? k0 : (row16 == 2 ? k0 + k1 : k0 + k1 + k2))) + in - c[hf];
+                }
+                const uint32_t gk = tot[0] + tot[1];
+                const bool fits = fill + gk <= LIST_CAP;
+                if (lane == 0) {
+                    if (halves) L.meta[qi] = fits ? (fill | (gk << 16)) : META_SLOW;
+                    else {
+                        L.meta[qs[0]] = fits ? (fill | (tot[0] << 16)) : META_SLOW;
+                        if (qs[1] < 64u) L.meta[qs[1]] = fits ? ((fill + tot[0]) | (tot[1] << 16)) : META_SLOW;
+                    }
+                }
+                if (fits) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        if (tot[hf] == 0) continue;                       // wave-uniform: no top row in this slot
+                        const uint32_t vo = c[hf] ? voff[hf] : 0xFFFFFFF0u;
+                        const u32x4 vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, vo, 0, STREAM_AUX);
+                        u32x4 vp01, vp23;
+                        if (PID32) { vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo, 0, STREAM_AUX); vp23 = vp01; }
+                        else {
+                            const uint32_t vo2 = c[hf] ? voff[hf] * 2u : 0xFFFFFFE0u;
+                            vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo2, 0, STREAM_AUX);
+                            vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo2 + 16u, 0, STREAM_AUX);
+                        }
+                        const u32x4 valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, vo, 0, STREAM_AUX);
+                        const u32x4 vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, vo, 0, STREAM_AUX);
+                        uint32_t idx = fill + (hf ? tot[0] : 0u) + slot[hf];   // file order: first slot, then second
+                        const uint32_t xt[4] = {vtax.x, vtax.y, vtax.z, vtax.w}, xa[4] = {valn.x, valn.y, valn.z, valn.w};
+                        const uint32_t xc[4] = {vacc.x, vacc.y, vacc.z, vacc.w};
+                        const uint32_t xm[4] = {vp01.x, vp01.y, vp01.z, vp01.w};
+                        const uint32_t xlo[4] = {vp01.x, vp01.z, vp23.x, vp23.z}, xhi[4] = {vp01.y, vp01.w, vp23.y, vp23.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if ((tmask[hf] >> r) & 1u) {
+                                Entry e;
+                                e.id = xt[r]; e.aln = xa[r]; e.acc = xc[r]; e.pq = ro[hf] + sub4 + r;
+                                e.p0 = PID32 ? xm[r] : xlo[r];
+                                e.p1 = PID32 ? 0u : xhi[r];
+                                L.list[idx] = e;
+                                ++idx;
+                            }
+                        }
+                    }
+                    fill += gk;
+                }
+            }
+        };
         {
-            const uint32_t longest = wave_max_u32(L.seg[lane].y);   // rows of the task's longest in-task segment
-            if (longest <= 16u) phase1(std::integral_constant<uint32_t, 4>());
-            else if (longest <= 32u) phase1(std::integral_constant<uint32_t, 8>());
-            else if (longest <= 64u) phase1(std::integral_constant<uint32_t, 16>());
-            else if (longest <= 128u) phase1(std::integral_constant<uint32_t, 32>());
-            else phase1(std::integral_constant<uint32_t, 64>());
+            const uint32_t rows = L.seg[lane].y;                    // this lane's query (0: empty, too long, or outside the span)
+            const uint32_t longest = wave_max_u32(rows > SHORT_SEG ? 0u : rows);   // longest streamed segment of the task
+            if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>());   // the C3 shape, specialised
+            else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u));
+            const uint64_t long_mask = __ballot(rows > SHORT_SEG);
+            if (long_mask) phase1_long(long_mask);                // after the streamed pass: it overwrites their (empty) list heads
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -490,20 +593,20 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             if (nrows == 0) { pack_status(ra, rb, BLU_ST_NO_HITS, 0xFFFFFFFFu); rec_kind = 1; }   // mod.rs:107-113
             else if (nrows > MAX_TASK_SEG || !in_span || (m & META_SLOW)) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
             else {
-                const uint32_t first = m & 0xFFFF, k = (m >> 16) & 0x1FF;
+                const uint32_t first = m & 0xFFFF, k = (m >> 16) & 0x3FF;
                 // parse errors first, in file order (find_single_query_consensus.rs:51-64), then NaN pident
                 uint32_t err = 0, err_pos = 0;
                 for (uint32_t e = 0; e < k; ++e) {
                     const uint32_t id = L.list[first + e].id;
                     if (err == 0 && ((id & ROW_MASK) >= t.n_tax || (id >> BLU_ROW_BITS) == 0)) {
                         err = (id & ROW_MASK) >= t.n_tax ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE;
-                        err_pos = L.list[first + e].pq & 0xFF;
+                        err_pos = L.list[first + e].pq;
                     }
                 }
                 if (!PID32 && err == 0)
                     for (uint32_t e = 0; e < k; ++e) {
                         const double p = __hiloint2double((int)L.list[first + e].p1, (int)L.list[first + e].p0);
-                        if (err == 0 && p != p) { err = BLU_ST_ERR_BAD_PIDENT; err_pos = L.list[first + e].pq & 0xFF; }
+                        if (err == 0 && p != p) { err = BLU_ST_ERR_BAD_PIDENT; err_pos = L.list[first + e].pq; }
                     }
                 if (err) { pack_status(ra, rb, err, row0 + err_pos); rec_kind = 1; }
                 else {
@@ -527,7 +630,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                         b_aln = take ? (int)x.aln : b_aln;
                         b_acc = take ? x.acc : b_acc;
                         r_row = take ? pos : r_row;
-                        r_pos = take ? (x.pq & 0xFF) : r_pos;
+                        r_pos = take ? x.pq : r_pos;
                     }
                     mode = k == 1 ? 2u : 0u;
                     g_lo = lo; g_hi = hi;    // span of the group in sorted order: phase 2c turns it into the shared levels
