@@ -6,7 +6,8 @@
 //
 // Kernel A  blu_consensus_stream_kernel — the streaming path (segments <= 512 hits).
 //   A wave task is 64 consecutive queries; the waves of a block take consecutive tasks.
-//   phase 1 (lane = 4 consecutive hit rows; 4 .. 64 lanes per query, chosen per task from its longest segment):
+//   phase 1 (lane = 4 consecutive hit rows; segments up to 128 rows streamed with 4 .. 32 lanes per query, chosen per
+//     task; segments of 129 .. 512 rows in a sparse long pass: bit-scores first, other columns for top rows only):
 //     16-byte buffer loads of the five SoA columns, M = max bit_score by a 16-lane
 //     DPP row reduction, top rows ranked by a DPP row scan and compacted in file
 //     order into a per-wave LDS list (row id, align_len, accession rank, position,
