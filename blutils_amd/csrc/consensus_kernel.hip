@@ -233,7 +233,9 @@ __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
 static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 
 #define META_SLOW 0x80000000u
+#ifndef SHORT_SEG
 #define SHORT_SEG 128u           // segments up to here are streamed (4 .. 32 lanes per query); longer ones take the sparse long pass
+#endif
 #define MAX_TASK_SEG 512u        // longest segment the stream kernel takes (64 lanes x 4 rows, twice); longer ones go to the worklist
 #ifndef BLOCK_B
 #define BLOCK_B 256
