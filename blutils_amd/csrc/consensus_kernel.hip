@@ -270,7 +270,7 @@ struct WaveLds {
 #define BLU_STEP_SETS 2
 #endif
 #ifndef BLU_WAVES_PER_SIMD
-#define BLU_WAVES_PER_SIMD 1
+#define BLU_WAVES_PER_SIMD 4   // 128 VGPRs: two 512-thread blocks per CU
 #endif
 template <int STRAT, bool PID32>
 __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
@@ -344,9 +344,13 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         // short segments do not leave most lanes without a row to load and long ones still share the lane-per-query
         // finalisation of phase 2.
         struct StepRegs { u32x4 vbs, vtax, vp01, vp23, valn, vacc; int left; uint32_t qi; };
-        auto phase1 = [&](const auto lpq) {                       // wave-uniform width: a constant for 16 lanes, a variable otherwise
+        auto phase1 = [&](const auto lpq, const bool sparse8) {   // wave-uniform width: a constant for 16 lanes, a variable otherwise
         const uint32_t LPQ = lpq;
         const uint32_t QPS = WAVE / LPQ;                          // queries per step
+        // From 25-row segments on, the step is two-staged: bit-scores first, then the other four columns only in the lanes
+        // that hold a top row (the others get an offset the descriptor rejects: no memory access).  Lines without a top
+        // row are never fetched; measured on C3 (50 hits): 2.24 -> 1.82 ms; at 30 hits -6 %, at 20 hits +3 % (hence 25).
+        const bool sparse = LPQ >= 16u || sparse8;
         const uint32_t grp = (uint32_t)lane / LPQ, sub4 = ((uint32_t)lane & (LPQ - 1u)) * 4u, row16 = (uint32_t)lane >> 4;
         // the loads of one step; lanes past the end of the segment get an offset the descriptor's range check
         // rejects: no memory access, no branch around the loads (so the wait counts below are exact).  No VALU write
@@ -358,6 +362,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             R.left = (sg.y > SHORT_SEG ? 0 : (int)sg.y) - (int)sub4;
             const uint32_t voff = R.left > 0 ? (sg.x + sub4) * 4u : 0xFFFFFFF0u;
             R.vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
+            if (sparse) return;                                  // the other columns: for top rows only, in process()
             R.vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, voff, 0, STREAM_AUX);
             if (PID32) {
                 R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff, 0, STREAM_AUX);   // four milli-percent values
@@ -369,10 +374,15 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             R.valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, voff, 0, STREAM_AUX);
             R.vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, voff, 0, STREAM_AUX);
         };
-        auto process = [&](const StepRegs& R) {
+        // per step: what the second half (writing the list entries) needs from the first (scores -> top rows)
+        struct StepTops { uint32_t idx0, tmask; bool fits; };
+        // first half of a step: top score, top rows, list slots; in sparse mode the other four columns are requested here,
+        // for the lanes that hold a top row only, so that the requests of all the steps of an iteration are in flight
+        // together
+        auto tops = [&](StepRegs& R, StepTops& T) {
             const int left = R.left;
             const uint32_t qi = R.qi;
-            const u32x4 vbs = R.vbs, vtax = R.vtax, vp01 = R.vp01, vp23 = R.vp23, valn = R.valn, vacc = R.vacc;
+            const u32x4 vbs = R.vbs;
             const int b0 = left > 0 ? (int)vbs.x : INT_MIN, b1 = left > 1 ? (int)vbs.y : INT_MIN;
             const int b2 = left > 2 ? (int)vbs.z : INT_MIN, b3 = left > 3 ? (int)vbs.w : INT_MIN;
             int M = imax(imax(b0, b1), imax(b2, b3));
@@ -408,10 +418,29 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 gk += (uint32_t)dpp<0x4E>((int)gk);
                 if (LPQ >= 8) gk += (uint32_t)dpp<0x141>((int)gk);
             }
-            const uint32_t idx0 = rbase + incl - c;               // list slot of this lane's first top row (file order)
-            if (sub4 == 0) L.meta[qi] = fits ? (idx0 | (gk << 16)) : META_SLOW;   // first lane of the query: its exclusive prefix
-            uint32_t idx = idx0;
-            const bool tt[4] = {t0, t1, t2, t3};
+            if (sparse && fits) {
+                const uint32_t voff_again = (L.seg[qi].x + sub4) * 4u;   // (recomputed rather than kept in a register across the wait)
+                const uint32_t vo = c ? voff_again : 0xFFFFFFF0u;
+                R.vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, vo, 0, STREAM_AUX);
+                if (PID32) { R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo, 0, STREAM_AUX); R.vp23 = R.vp01; }
+                else {
+                    const uint32_t vo2 = c ? voff_again * 2u : 0xFFFFFFE0u;
+                    R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo2, 0, STREAM_AUX);
+                    R.vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo2 + 16u, 0, STREAM_AUX);
+                }
+                R.valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, vo, 0, STREAM_AUX);
+                R.vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, vo, 0, STREAM_AUX);
+            }
+            T.idx0 = rbase + incl - c;                            // list slot of this lane's first top row (file order)
+            T.tmask = (uint32_t)t0 | ((uint32_t)t1 << 1) | ((uint32_t)t2 << 2) | ((uint32_t)t3 << 3);
+            T.fits = fits;
+            if (sub4 == 0) L.meta[qi] = fits ? (T.idx0 | (gk << 16)) : META_SLOW;   // first lane of the query: its exclusive prefix
+            if (fits) fill = p3 + k3;
+        };
+        // second half: the top rows' entries, in file order
+        auto emit = [&](const StepRegs& R, const StepTops& T) {
+            const u32x4 vtax = R.vtax, vp01 = R.vp01, vp23 = R.vp23, valn = R.valn, vacc = R.vacc;
+            uint32_t idx = T.idx0;
             const uint32_t xt[4] = {vtax.x, vtax.y, vtax.z, vtax.w}, xa[4] = {valn.x, valn.y, valn.z, valn.w};
             const uint32_t xc[4] = {vacc.x, vacc.y, vacc.z, vacc.w};
             const uint32_t xm[4] = {vp01.x, vp01.y, vp01.z, vp01.w};   // PID32 layout
@@ -421,7 +450,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
 #ifdef BLU_EXP_NOLDS
                 if (false) {
 #else
-                if (fits && tt[r]) {
+                if (T.fits && ((T.tmask >> r) & 1u)) {
 #endif
                     Entry e;
                     e.id = xt[r]; e.aln = xa[r]; e.acc = xc[r]; e.pq = sub4 + r;
@@ -431,22 +460,33 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     ++idx;
                 }
             }
-            if (fits) fill = p3 + k3;
         };
         // BLU_STEP_SETS steps have their loads issued together before the first one is processed: the wave keeps
-        // SETS x 5 KiB in flight instead of 5 KiB
+        // SETS x 5 KiB (dense) in flight instead of 5 KiB
         for (uint32_t qb = 0; qb < nq; qb += QPS * BLU_STEP_SETS) {
             StepRegs R[BLU_STEP_SETS];
+            StepTops T[BLU_STEP_SETS];
 #pragma unroll
             for (int u = 0; u < BLU_STEP_SETS; ++u) issue(qb + QPS * u, R[u]);
-#pragma unroll
-            for (int u = 0; u < BLU_STEP_SETS; ++u) {
-                // every loaded register is read here on every path (otherwise hipcc parks a vmcnt(0) at the loop head)
-                asm volatile("" ::"v"(R[u].vbs), "v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc));
 #ifndef BLU_EXP_NOREDUCE
-                process(R[u]);
-#endif
+            if (sparse) {
+#pragma unroll
+                for (int u = 0; u < BLU_STEP_SETS; ++u) { asm volatile("" ::"v"(R[u].vbs)); tops(R[u], T[u]); }
+#pragma unroll
+                for (int u = 0; u < BLU_STEP_SETS; ++u) {
+                    asm volatile("" ::"v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc));
+                    emit(R[u], T[u]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < BLU_STEP_SETS; ++u) {
+                    // every loaded register is read here on every path (otherwise hipcc parks a vmcnt(0) at the loop head)
+                    asm volatile("" ::"v"(R[u].vbs), "v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc));
+                    tops(R[u], T[u]);
+                    emit(R[u], T[u]);
+                }
             }
+#endif
         }
         };
         // Segments of 129..512 rows: a step holds two 256-row slots — two queries, or the two halves of one query longer
@@ -553,8 +593,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         {
             const uint32_t rows = L.seg[lane].y;                    // this lane's query (0: empty, too long, or outside the span)
             const uint32_t longest = wave_max_u32(rows > SHORT_SEG ? 0u : rows);   // longest streamed segment of the task
-            if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>());   // the C3 shape, specialised
-            else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u));
+            if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>(), false);   // the C3 shape, specialised
+            else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u), longest >= 25u);
             const uint64_t long_mask = __ballot(rows > SHORT_SEG);
             if (long_mask) phase1_long(long_mask);                // after the streamed pass: it overwrites their (empty) list heads
         }
