@@ -463,6 +463,34 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         };
         // BLU_STEP_SETS steps have their loads issued together before the first one is processed: the wave keeps
         // SETS x 5 KiB (dense) in flight instead of 5 KiB
+#ifndef BLU_EXP_NOPIPE
+        if (sparse) {
+            // two-stage steps, software-pipelined: while the second-stage requests of iteration i are in flight, the
+            // bit-scores of iteration i+1 are requested, so a wave pays one exposed round trip per iteration, not two
+            StepRegs R[BLU_STEP_SETS];
+            StepTops T[BLU_STEP_SETS];
+#pragma unroll
+            for (int u = 0; u < BLU_STEP_SETS; ++u) issue(QPS * u, R[u]);
+            for (uint32_t qb = 0; qb < nq; qb += QPS * BLU_STEP_SETS) {
+#pragma unroll
+                for (int u = 0; u < BLU_STEP_SETS; ++u) { asm volatile("" ::"v"(R[u].vbs)); tops(R[u], T[u]); }
+                StepRegs N[BLU_STEP_SETS];
+                const bool more = qb + QPS * BLU_STEP_SETS < nq;
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < BLU_STEP_SETS; ++u) issue(qb + QPS * BLU_STEP_SETS + QPS * u, N[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < BLU_STEP_SETS; ++u) {
+                    asm volatile("" ::"v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc));
+                    emit(R[u], T[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < BLU_STEP_SETS; ++u) { asm volatile("" ::"v"(N[u].vbs)); R[u].vbs = N[u].vbs; R[u].left = N[u].left; R[u].qi = N[u].qi; }
+            }
+            return;
+        }
+#endif
         for (uint32_t qb = 0; qb < nq; qb += QPS * BLU_STEP_SETS) {
             StepRegs R[BLU_STEP_SETS];
             StepTops T[BLU_STEP_SETS];
