@@ -27,6 +27,11 @@ CUSTOM_16S = {"domain": 50, "kingdom": 60, "phylum": 75, "class": 80, "order": 8
               "species": 99}   # reference assets/custom-taxon-cutoffs-bacteria-16S.yaml
 
 
+LAYOUT_TEXT = {"packed": "bit-score column + 16-byte side records, perc_identity as milli-percent u32 (lossless, 20 B/hit)",
+               "milli": "five columns, perc_identity as milli-percent u32 (lossless, 20 B/hit)",
+               "f64": "five columns, perc_identity as f64 (24 B/hit)"}
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -46,9 +51,11 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank holds the full per-GPU workload; strong: the workload is split over the ranks "
                          "(BASELINE config #4: 10M queries sharded across 8 GPUs)")
-    ap.add_argument("--pident", default="milli", choices=["milli", "f64"],
-                    help="hit-table layout: perc_identity as milli-percent u32 (lossless for BLAST's 3-decimal values, "
-                         "20 B/hit) or as f64 (24 B/hit, the canonical layout of BASELINE.md)")
+    ap.add_argument("--pident", default="packed", choices=["packed", "milli", "f64"],
+                    help="hit-table layout: packed = bit-score column + 16-byte side records {tax_row, pident_milli, "
+                         "align_len, acc_rank} (20 B/hit; a top row's values sit in one memory line); milli = five "
+                         "columns with perc_identity as milli-percent u32 (20 B/hit); f64 = five columns with "
+                         "perc_identity as f64 (24 B/hit, the canonical layout of BASELINE.md)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one run (both kernels) in a HIP graph and time replays: for launch-bound sizes (C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,12 +101,12 @@ def main():
     t_up = time.time() - t0
     t0 = time.time()
     hits = synth.make_hits(tax, cfg["n_queries"], seed, cfg["hits_per_query"], zipf=cfg["zipf"], device=dev,
-                           q_offset=rank * cfg["n_queries"], columns=args.pident)
+                           q_offset=rank * cfg["n_queries"], columns="f64" if args.pident == "f64" else "milli")
     torch.cuda.synchronize()
     t_hits = time.time() - t0
     Q, Hn = hits.n_queries, hits.n_hits
     out = torch.zeros(32 * Q, dtype=torch.uint8, device=dev)
-    hd = hits.as_dict(args.pident)
+    hd = hits.as_dict("f64" if args.pident == "f64" else "milli")
     # the join of the hit table with the taxonomy (mod.rs:72-76): desc row -> engine row id, done once at ingest.
     # The oracle legs read the desc rows of the sampled prefix, kept aside.
     S_keep = min(Q, max(args.cpu_sample, 1))
@@ -107,6 +114,10 @@ def main():
     for a in range(0, Hn, 1 << 26):
         b = min(Hn, a + (1 << 26))
         hd["tax_row"][a:b] = eng_tax.engine_rows(hd["tax_row"][a:b])
+    cols = hd            # the five columns (kept for the oracle sample below)
+    if args.pident == "packed":
+        hits.tax_row = hd["tax_row"]
+        hd = hits.as_dict("packed")
     if rank == 0:
         log(f"[bench] taxonomy {tax.n} taxids ({t_tax:.1f}s gen, {t_up:.1f}s upload, {eng_tax.n_shapes} shapes, "
             f"depth<={eng_tax.max_depth}, {eng_tax.device_bytes / 1e6:.0f} MB on device); "
@@ -124,9 +135,9 @@ def main():
         S = min(Q, max(args.cpu_sample, 1))
         seg = hits.seg_off[: S + 1].cpu().numpy()
         nrow = int(seg[-1])
-        samp = {k: v[:nrow].cpu().numpy() for k, v in hd.items() if k not in ("seg_off", "tax_row")}
+        samp = {k: v[:nrow].cpu().numpy() for k, v in cols.items() if k not in ("seg_off", "tax_row")}
         samp["tax_row"] = desc_rows_sample[:nrow]
-        if args.pident == "milli":   # the oracle reads the f64 the reference's parser would produce: k / 1000, correctly rounded
+        if args.pident != "f64":   # the oracle reads the f64 the reference's parser would produce: k / 1000, correctly rounded
             samp["pident"] = samp.pop("pident_milli").astype(np.float64) / 1000.0
         got = engine.records_from_tensor(out[: 32 * S])
         exp = orc.columnar_run(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, seg, samp["bitscore"],
@@ -195,7 +206,7 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile) and not (args.queries or args.taxa or args.hits_per_query):
             try:
-                tkey = args.config if args.pident == "f64" else args.config + "-milli"
+                tkey = args.config if args.pident == "f64" else args.config + "-" + args.pident
                 traffic = json.load(open(tfile)).get(tkey, {}).get("traffic_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -213,9 +224,9 @@ def main():
             "config": {"workload": f"{args.config}: {Q} queries x "
                                    f"{cfg['hits_per_query'] if cfg['zipf'] is None else 'Zipf' + str(cfg['zipf'])} hits per GPU, "
                                    f"{tax.n}-taxid synthetic taxonomy, strategy {args.strategy}, taxon {args.taxon}, "
-                                   f"perc_identity column {'milli-percent u32 (lossless, 20 B/hit)' if args.pident == 'milli' else 'f64 (24 B/hit)'}",
+                                   f"layout {LAYOUT_TEXT[args.pident]}",
                        "queries_per_gpu": Q, "hit_rows_per_gpu": Hn, "taxids": tax.n, "strategy": args.strategy,
-                       "taxon": args.taxon, "pident_layout": args.pident, "bytes_per_hit": 20 if args.pident == "milli" else 24, "seed": hex(seed), "generator_version": synth.GENERATOR_VERSION,
+                       "taxon": args.taxon, "pident_layout": args.pident, "bytes_per_hit": 24 if args.pident == "f64" else 20, "seed": hex(seed), "generator_version": synth.GENERATOR_VERSION,
                        "parallelism": f"query-sharded x{world}, taxonomy replicated, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

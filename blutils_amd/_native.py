@@ -44,7 +44,7 @@ class TaxonomyDesc(C.Structure):
 class Hits(C.Structure):
     _fields_ = [("bitscore", C.c_void_p), ("tax_row", C.c_void_p), ("pident", C.c_void_p), ("align_len", C.c_void_p),
                 ("acc_rank", C.c_void_p), ("seg_off", C.c_void_p), ("n_hits", C.c_uint64), ("n_queries", C.c_uint64),
-                ("on_device", C.c_int32), ("reserved", C.c_int32), ("pident_milli", C.c_void_p)]
+                ("on_device", C.c_int32), ("reserved", C.c_int32), ("pident_milli", C.c_void_p), ("packed", C.c_void_p)]
 
 
 class RunParams(C.Structure):

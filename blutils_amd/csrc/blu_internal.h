@@ -67,6 +67,7 @@ struct HitsDev {
     const uint32_t* tax_row;
     const double* pident;          // f64 layout, or nullptr
     const uint32_t* pident_milli;  // milli-percent layout, or nullptr
+    const uint32_t* packed;        // packed layout: 4 words per hit {tax_row, pident_milli, align_len, acc_rank}, or nullptr
     const int32_t* align_len;
     const uint32_t* acc_rank;
     const uint64_t* seg_off;

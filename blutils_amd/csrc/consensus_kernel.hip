@@ -241,7 +241,7 @@ static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 #define BLOCK_B 256
 #endif
 #define LONG_SPAN (1u << 28)    // rows one bit-score descriptor of the worklist kernel covers
-#define TASK_SPAN (1ull << 28)   // rows one task's buffer descriptors cover
+#define TASK_SPAN (1ull << 27)   // rows one task's buffer descriptors cover
 #define CUT_LDS 512        // distinct cutoff values kept in LDS (4 KiB); larger tables are read from global memory
 #define ROW_MASK ((1u << BLU_ROW_BITS) - 1u)
 // the five hit columns are read exactly once per run: non-temporal loads keep them from displacing the
@@ -272,10 +272,13 @@ struct WaveLds {
 #ifndef BLU_WAVES_PER_SIMD
 #define BLU_WAVES_PER_SIMD 4   // 128 VGPRs: two 512-thread blocks per CU
 #endif
-template <int STRAT, bool PID32>
+// LAYOUT: 0 = perc_identity f64 column, 1 = milli-percent u32 column, 2 = packed 16-byte side records
+// {tax_row, pident_milli, align_len, acc_rank} next to the bit-score column
+template <int STRAT, int LAYOUT>
 __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                        uint32_t* __restrict__ worklist,
                                                                        uint32_t* __restrict__ work_count) {
+    constexpr bool PID32 = LAYOUT != 0, PACKED = LAYOUT == 2;
     // work_count = {queue length, blocks done, published length}: the first two are zero on entry and on exit
     __shared__ WaveLds s_lds[WAVES_A];
     // the distinct cutoff values of this (taxonomy, backbone): a few hundred doubles, read per level in phase 2c
@@ -325,10 +328,12 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         const uint64_t rem = (h.n_hits - task_start) < TASK_SPAN ? (h.n_hits - task_start) : TASK_SPAN;
         const uint32_t rem4 = (uint32_t)(rem * 4), rem8 = (uint32_t)(rem * 8);
         const auto rs_bs = __builtin_amdgcn_make_buffer_rsrc((void*)(h.bitscore + task_start), 0, rem4, 0x00020000);
-        const auto rs_tax = __builtin_amdgcn_make_buffer_rsrc((void*)(h.tax_row + task_start), 0, rem4, 0x00020000);
+        // (packed layout: rs_tax is the descriptor of the 16-byte records; the other three column descriptors are unused)
+        const auto rs_tax = PACKED ? __builtin_amdgcn_make_buffer_rsrc((void*)(h.packed + 4 * task_start), 0, (uint32_t)(rem * 16), 0x00020000)
+                                   : __builtin_amdgcn_make_buffer_rsrc((void*)(h.tax_row + task_start), 0, rem4, 0x00020000);
         const auto rs_aln = __builtin_amdgcn_make_buffer_rsrc((void*)(h.align_len + task_start), 0, rem4, 0x00020000);
         const auto rs_acc = __builtin_amdgcn_make_buffer_rsrc((void*)(h.acc_rank + task_start), 0, rem4, 0x00020000);
-        const auto rs_pid = PID32 ? __builtin_amdgcn_make_buffer_rsrc((void*)(h.pident_milli + task_start), 0, rem4, 0x00020000)
+        const auto rs_pid = PACKED ? rs_tax : PID32 ? __builtin_amdgcn_make_buffer_rsrc((void*)(h.pident_milli + task_start), 0, rem4, 0x00020000)
                                   : __builtin_amdgcn_make_buffer_rsrc((void*)(h.pident + task_start), 0, rem8, 0x00020000);
         // per-query {first row, row count} of the task, relative to task_start; count 0 also for segments > 64 rows
         // (those go to the worklist in phase 2a) so that phase 1 simply finds no top row in them
@@ -344,6 +349,52 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         // short segments do not leave most lanes without a row to load and long ones still share the lane-per-query
         // finalisation of phase 2.
         struct StepRegs { u32x4 vbs, vtax, vp01, vp23, valn, vacc; int left; uint32_t qi; };
+        // The non-bit-score values of a lane's four rows.  Column layouts: one 16-byte load per column (vtax, vp01[/vp23],
+        // valn, vacc = the column's four rows).  Packed layout: one 16-byte load per ROW (vtax, vp01, valn, vacc = rows
+        // 0..3, each {tax_row, pident_milli, align_len, acc_rank}), and only the rows in `rows` are requested.
+        // voff = byte offset of the lane's first row in a 4-byte column, or the out-of-range sentinel.
+        auto fetch_rest = [&](StepRegs& R, const uint32_t voff, const uint32_t rows) {
+            const bool any = voff != 0xFFFFFFF0u && rows != 0u;
+            if (PACKED) {
+                const uint32_t base = voff * 4u;
+                R.vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, (any && (rows & 1u)) ? base : 0xFFFFFFC0u, 0, STREAM_AUX);
+                R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, (any && (rows & 2u)) ? base + 16u : 0xFFFFFFC0u, 0, STREAM_AUX);
+                R.valn = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, (any && (rows & 4u)) ? base + 32u : 0xFFFFFFC0u, 0, STREAM_AUX);
+                R.vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, (any && (rows & 8u)) ? base + 48u : 0xFFFFFFC0u, 0, STREAM_AUX);
+                R.vp23 = R.vp01;
+                return;
+            }
+            const uint32_t vo = any ? voff : 0xFFFFFFF0u;
+            R.vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, vo, 0, STREAM_AUX);
+            if (PID32) {
+                R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo, 0, STREAM_AUX);   // four milli-percent values
+                R.vp23 = R.vp01;
+            } else {
+                const uint32_t vo2 = any ? voff * 2u : 0xFFFFFFE0u;
+                R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo2, 0, STREAM_AUX);
+                R.vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo2 + 16u, 0, STREAM_AUX);
+            }
+            R.valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, vo, 0, STREAM_AUX);
+            R.vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, vo, 0, STREAM_AUX);
+        };
+        // row r of the lane as a list entry
+        auto make_entry = [&](const StepRegs& R, const int r, const uint32_t pos) {
+            Entry e;
+            if (PACKED) {
+                const u32x4 rec = r == 0 ? R.vtax : (r == 1 ? R.vp01 : (r == 2 ? R.valn : R.vacc));
+                e.id = rec.x; e.p0 = rec.y; e.p1 = 0u; e.aln = rec.z; e.acc = rec.w;
+            } else {
+                const uint32_t xt[4] = {R.vtax.x, R.vtax.y, R.vtax.z, R.vtax.w}, xa[4] = {R.valn.x, R.valn.y, R.valn.z, R.valn.w};
+                const uint32_t xc[4] = {R.vacc.x, R.vacc.y, R.vacc.z, R.vacc.w};
+                const uint32_t xm[4] = {R.vp01.x, R.vp01.y, R.vp01.z, R.vp01.w};   // milli-percent column
+                const uint32_t xlo[4] = {R.vp01.x, R.vp01.z, R.vp23.x, R.vp23.z}, xhi[4] = {R.vp01.y, R.vp01.w, R.vp23.y, R.vp23.w};   // f64 column
+                e.id = xt[r]; e.aln = xa[r]; e.acc = xc[r];
+                e.p0 = PID32 ? xm[r] : xlo[r];
+                e.p1 = PID32 ? 0u : xhi[r];
+            }
+            e.pq = pos;
+            return e;
+        };
         auto phase1 = [&](const auto lpq, const bool sparse8) {   // wave-uniform width: a constant for 16 lanes, a variable otherwise
         const uint32_t LPQ = lpq;
         const uint32_t QPS = WAVE / LPQ;                          // queries per step
@@ -362,17 +413,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             R.left = (sg.y > SHORT_SEG ? 0 : (int)sg.y) - (int)sub4;
             const uint32_t voff = R.left > 0 ? (sg.x + sub4) * 4u : 0xFFFFFFF0u;
             R.vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
-            if (sparse) return;                                  // the other columns: for top rows only, in process()
-            R.vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, voff, 0, STREAM_AUX);
-            if (PID32) {
-                R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff, 0, STREAM_AUX);   // four milli-percent values
-                R.vp23 = R.vp01;
-            } else {
-                R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u, 0, STREAM_AUX);
-                R.vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, voff * 2u + 16u, 0, STREAM_AUX);
-            }
-            R.valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, voff, 0, STREAM_AUX);
-            R.vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, voff, 0, STREAM_AUX);
+            if (sparse) return;                                  // the other columns: for top rows only, in tops()
+            fetch_rest(R, voff, 0xFu);
         };
         // per step: what the second half (writing the list entries) needs from the first (scores -> top rows)
         struct StepTops { uint32_t idx0, tmask; bool fits; };
@@ -418,33 +460,17 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 gk += (uint32_t)dpp<0x4E>((int)gk);
                 if (LPQ >= 8) gk += (uint32_t)dpp<0x141>((int)gk);
             }
-            if (sparse && fits) {
-                const uint32_t voff_again = (L.seg[qi].x + sub4) * 4u;   // (recomputed rather than kept in a register across the wait)
-                const uint32_t vo = c ? voff_again : 0xFFFFFFF0u;
-                R.vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, vo, 0, STREAM_AUX);
-                if (PID32) { R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo, 0, STREAM_AUX); R.vp23 = R.vp01; }
-                else {
-                    const uint32_t vo2 = c ? voff_again * 2u : 0xFFFFFFE0u;
-                    R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo2, 0, STREAM_AUX);
-                    R.vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo2 + 16u, 0, STREAM_AUX);
-                }
-                R.valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, vo, 0, STREAM_AUX);
-                R.vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, vo, 0, STREAM_AUX);
-            }
+            const uint32_t tmask = (uint32_t)t0 | ((uint32_t)t1 << 1) | ((uint32_t)t2 << 2) | ((uint32_t)t3 << 3);
+            if (sparse && fits) fetch_rest(R, (L.seg[qi].x + sub4) * 4u, tmask);   // (offset recomputed rather than kept across the wait)
             T.idx0 = rbase + incl - c;                            // list slot of this lane's first top row (file order)
-            T.tmask = (uint32_t)t0 | ((uint32_t)t1 << 1) | ((uint32_t)t2 << 2) | ((uint32_t)t3 << 3);
+            T.tmask = tmask;
             T.fits = fits;
             if (sub4 == 0) L.meta[qi] = fits ? (T.idx0 | (gk << 16)) : META_SLOW;   // first lane of the query: its exclusive prefix
             if (fits) fill = p3 + k3;
         };
         // second half: the top rows' entries, in file order
         auto emit = [&](const StepRegs& R, const StepTops& T) {
-            const u32x4 vtax = R.vtax, vp01 = R.vp01, vp23 = R.vp23, valn = R.valn, vacc = R.vacc;
             uint32_t idx = T.idx0;
-            const uint32_t xt[4] = {vtax.x, vtax.y, vtax.z, vtax.w}, xa[4] = {valn.x, valn.y, valn.z, valn.w};
-            const uint32_t xc[4] = {vacc.x, vacc.y, vacc.z, vacc.w};
-            const uint32_t xm[4] = {vp01.x, vp01.y, vp01.z, vp01.w};   // PID32 layout
-            const uint32_t xlo[4] = {vp01.x, vp01.z, vp23.x, vp23.z}, xhi[4] = {vp01.y, vp01.w, vp23.y, vp23.w};   // f64 layout
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #ifdef BLU_EXP_NOLDS
@@ -452,17 +478,11 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
 #else
                 if (T.fits && ((T.tmask >> r) & 1u)) {
 #endif
-                    Entry e;
-                    e.id = xt[r]; e.aln = xa[r]; e.acc = xc[r]; e.pq = sub4 + r;
-                    e.p0 = PID32 ? xm[r] : xlo[r];
-                    e.p1 = PID32 ? 0u : xhi[r];
-                    L.list[idx] = e;   // the row id carries the lineage length: phase 1 touches no taxonomy table
+                    L.list[idx] = make_entry(R, r, sub4 + r);   // the row id carries the lineage length: phase 1 touches no taxonomy table
                     ++idx;
                 }
             }
         };
-        // BLU_STEP_SETS steps have their loads issued together before the first one is processed: the wave keeps
-        // SETS x 5 KiB (dense) in flight instead of 5 KiB
 #ifndef BLU_EXP_NOPIPE
         if (sparse) {
             // two-stage steps, software-pipelined: while the second-stage requests of iteration i are in flight, the
@@ -586,30 +606,13 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         if (tot[hf] == 0) continue;                       // wave-uniform: no top row in this slot
-                        const uint32_t vo = c[hf] ? voff[hf] : 0xFFFFFFF0u;
-                        const u32x4 vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, vo, 0, STREAM_AUX);
-                        u32x4 vp01, vp23;
-                        if (PID32) { vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo, 0, STREAM_AUX); vp23 = vp01; }
-                        else {
-                            const uint32_t vo2 = c[hf] ? voff[hf] * 2u : 0xFFFFFFE0u;
-                            vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo2, 0, STREAM_AUX);
-                            vp23 = __builtin_amdgcn_raw_buffer_load_b128(rs_pid, vo2 + 16u, 0, STREAM_AUX);
-                        }
-                        const u32x4 valn = __builtin_amdgcn_raw_buffer_load_b128(rs_aln, vo, 0, STREAM_AUX);
-                        const u32x4 vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, vo, 0, STREAM_AUX);
+                        StepRegs S;
+                        fetch_rest(S, voff[hf], tmask[hf]);
                         uint32_t idx = fill + (hf ? tot[0] : 0u) + slot[hf];   // file order: first slot, then second
-                        const uint32_t xt[4] = {vtax.x, vtax.y, vtax.z, vtax.w}, xa[4] = {valn.x, valn.y, valn.z, valn.w};
-                        const uint32_t xc[4] = {vacc.x, vacc.y, vacc.z, vacc.w};
-                        const uint32_t xm[4] = {vp01.x, vp01.y, vp01.z, vp01.w};
-                        const uint32_t xlo[4] = {vp01.x, vp01.z, vp23.x, vp23.z}, xhi[4] = {vp01.y, vp01.w, vp23.y, vp23.w};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             if ((tmask[hf] >> r) & 1u) {
-                                Entry e;
-                                e.id = xt[r]; e.aln = xa[r]; e.acc = xc[r]; e.pq = ro[hf] + sub4 + r;
-                                e.p0 = PID32 ? xm[r] : xlo[r];
-                                e.p1 = PID32 ? 0u : xhi[r];
-                                L.list[idx] = e;
+                                L.list[idx] = make_entry(S, r, ro[hf] + sub4 + r);
                                 ++idx;
                             }
                         }
@@ -917,10 +920,11 @@ __device__ __forceinline__ int select_reference(bool valid, uint32_t len, uint32
     return first_lane(cand);
 }
 
-template <int STRAT, bool PID32>
+template <int STRAT, int LAYOUT>
 __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                  const uint32_t* __restrict__ worklist,
                                                                  const uint32_t* __restrict__ work_count) {
+    constexpr bool PID32 = LAYOUT != 0, PACKED = LAYOUT == 2;
     const int lane = lane_id();
     const uint32_t n_work = work_count[2];   // queue length published by the stream kernel's last block
     const uint32_t wave = blockIdx.x * (blockDim.x / WAVE) + __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
@@ -933,11 +937,12 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
         start = uniform64(start);
         const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)(end - start));   // n_hits < 2^32
         const int32_t* c_bs = h.bitscore + start;
-        const uint32_t* c_tax = h.tax_row + start;
+        const uint32_t* c_tax = PACKED ? nullptr : h.tax_row + start;
         const double* c_pid = PID32 ? nullptr : h.pident + start;
-        const uint32_t* c_pm = PID32 ? h.pident_milli + start : nullptr;
-        const int32_t* c_aln = h.align_len + start;
-        const uint32_t* c_acc = h.acc_rank + start;
+        const uint32_t* c_pm = (PID32 && !PACKED) ? h.pident_milli + start : nullptr;
+        const int32_t* c_aln = PACKED ? nullptr : h.align_len + start;
+        const uint32_t* c_acc = PACKED ? nullptr : h.acc_rank + start;
+        const u32x4* c_pk = PACKED ? reinterpret_cast<const u32x4*>(h.packed) + start : nullptr;   // 16-byte records
         // pass 1: top score
         // 16-byte loads, four per lane in flight (1024 rows per iteration); rows past the segment read as 0 from the
         // range-checked descriptor and are masked by index
@@ -990,10 +995,11 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
             k += (uint32_t)__builtin_popcountll(mask);
             const uint32_t i = (uint32_t)sb + iloc;                   // row index inside the segment
             const uint32_t ii = top ? i : 0;
-            const uint32_t tax = c_tax[ii];
-            const double pid = PID32 ? milli_to_f64(c_pm[ii]) : c_pid[ii];
-            const int aln = c_aln[ii];
-            const uint32_t acc = c_acc[ii];
+            uint32_t tax, acc;
+            int aln;
+            double pid;
+            if (PACKED) { const u32x4 rec = c_pk[ii]; tax = rec.x; pid = milli_to_f64(rec.y); aln = (int)rec.z; acc = rec.w; }
+            else { tax = c_tax[ii]; pid = PID32 ? milli_to_f64(c_pm[ii]) : c_pid[ii]; aln = c_aln[ii]; acc = c_acc[ii]; }
             const uint32_t pos = tax & ROW_MASK;
             const bool unmatched = top && pos >= t.n_tax;
             const uint32_t len = umin(tax >> BLU_ROW_BITS, t.max_depth);
@@ -1116,11 +1122,11 @@ void consensus_last_geometry(uint32_t* grid, uint32_t* block) {
     if (block) *block = g_block;
 }
 
-template <int STRAT, bool PID32>
+template <int STRAT, int LAYOUT>
 static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hipStream_t s, int num_cus,
                     uint32_t* worklist, uint32_t* work_count) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blu_consensus_stream_kernel<STRAT, PID32>, BLOCK_A, 0) != hipSuccess || per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blu_consensus_stream_kernel<STRAT, LAYOUT>, BLOCK_A, 0) != hipSuccess || per_cu <= 0)
         per_cu = 2;
     const uint64_t n_tasks = (hits.n_queries + WAVE - 1) / WAVE;
     const uint64_t want = (n_tasks + WAVES_A - 1) / WAVES_A;
@@ -1129,10 +1135,10 @@ static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hip
     if (grid == 0) grid = 1;
     g_grid = grid;
     g_block = BLOCK_A;
-    hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, PID32>), dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count);
+    hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT>), dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count);
     // 32 waves per CU: the kernel is latency-bound per query (block size 256 / 512 / 1024: 1.11 / 1.135 / 1.14 ms on C5)
     const uint32_t grid_b = (uint32_t)(num_cus > 0 ? num_cus : 256) * (2048u / BLOCK_B);
-    hipLaunchKernelGGL((blu_consensus_long_kernel<STRAT, PID32>), dim3(grid_b), dim3(BLOCK_B), 0, s, hits, tax, out, worklist, work_count);
+    hipLaunchKernelGGL((blu_consensus_long_kernel<STRAT, LAYOUT>), dim3(grid_b), dim3(BLOCK_B), 0, s, hits, tax, out, worklist, work_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("kernel launch failed: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
     return BLU_OK;
@@ -1142,13 +1148,16 @@ int launch_consensus(const TaxDev& tax, const HitsDev& hits, int strategy, blu_r
                      int num_cus, uint32_t* worklist, uint32_t* work_count) {
     (void)device;
     if (hits.n_queries == 0) return BLU_OK;
-    const bool milli = hits.pident_milli != nullptr;
+    const int layout = hits.packed ? 2 : (hits.pident_milli ? 1 : 0);
+    hipStream_t s = (hipStream_t)stream;
     if (strategy == BLU_RELAXED) {
-        if (milli) return launch_t<BLU_RELAXED, true>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count);
-        return launch_t<BLU_RELAXED, false>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count);
+        if (layout == 2) return launch_t<BLU_RELAXED, 2>(tax, hits, out, s, num_cus, worklist, work_count);
+        if (layout == 1) return launch_t<BLU_RELAXED, 1>(tax, hits, out, s, num_cus, worklist, work_count);
+        return launch_t<BLU_RELAXED, 0>(tax, hits, out, s, num_cus, worklist, work_count);
     }
-    if (milli) return launch_t<BLU_CAUTIOUS, true>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count);
-    return launch_t<BLU_CAUTIOUS, false>(tax, hits, out, (hipStream_t)stream, num_cus, worklist, work_count);
+    if (layout == 2) return launch_t<BLU_CAUTIOUS, 2>(tax, hits, out, s, num_cus, worklist, work_count);
+    if (layout == 1) return launch_t<BLU_CAUTIOUS, 1>(tax, hits, out, s, num_cus, worklist, work_count);
+    return launch_t<BLU_CAUTIOUS, 0>(tax, hits, out, s, num_cus, worklist, work_count);
 }
 
 }  // namespace blu

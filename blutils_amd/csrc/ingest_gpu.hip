@@ -723,6 +723,15 @@ __global__ void to_milli(const double* __restrict__ pid, uint64_t n, uint32_t* _
 }
 }  // namespace
 
+namespace {
+// 16-byte side records of the packed layout (include/blu_consensus.h: blu_hits.packed)
+__global__ void pack_side_records(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ milli, const int32_t* __restrict__ aln,
+                                  const uint32_t* __restrict__ acc, uint64_t n, uint4* __restrict__ rec) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rec[i] = make_uint4(rows[i], milli[i], (uint32_t)aln[i], acc[i]);
+}
+}  // namespace
+
 DeviceHits::~DeviceHits() {
     if (device < 0) return;
     (void)hipSetDevice(device);
@@ -735,6 +744,7 @@ int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_
     const bool oom_fallback = false;
     std::string* const oom_why = nullptr;
     uint32_t *d_fwd = nullptr, *d_milli = nullptr, *d_flag = nullptr;
+    uint4* d_rec = nullptr;
     blu_result* d_out = nullptr;
     uint32_t inexact = 0;
     const uint64_t n = dev.n_hits;
@@ -755,7 +765,13 @@ int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_
         blu_hits h{};
         h.bitscore = dev.bitscore; h.tax_row = dev.tax_desc_row; h.align_len = dev.align_len; h.acc_rank = dev.acc_rank;
         h.seg_off = (const uint64_t*)dev.seg_off;
-        if (inexact) h.pident = dev.pident; else h.pident_milli = d_milli;
+        if (inexact) h.pident = dev.pident;
+        else if (n && hipMalloc((void**)&d_rec, n * 16) == hipSuccess) {
+            // packed layout: a top row's four values in one memory line (if the records do not fit, the columns do)
+            hipLaunchKernelGGL(pack_side_records, grid(n), dim3(256), 0, 0, dev.tax_desc_row, d_milli, dev.align_len, dev.acc_rank, n, d_rec);
+            h.packed = (const uint32_t*)d_rec;
+            h.tax_row = nullptr; h.align_len = nullptr; h.acc_rank = nullptr;
+        } else { (void)hipGetLastError(); h.pident_milli = d_milli; }
         h.n_hits = n; h.n_queries = dev.n_queries; h.on_device = 1;
         blu_run_params rp{strategy, 0, nullptr};
         rc = blu_consensus_run(tax, &h, &rp, d_out);
@@ -763,7 +779,7 @@ int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_
     }
     HIPCHK(hipMemcpy(out, d_out, dev.n_queries * sizeof(blu_result), hipMemcpyDeviceToHost));   // waits for the null stream
 done:
-    for (void* p : {(void*)d_fwd, (void*)d_milli, (void*)d_flag, (void*)d_out}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)d_fwd, (void*)d_milli, (void*)d_flag, (void*)d_out, (void*)d_rec}) if (p) (void)hipFree(p);
     return rc;
 }
 

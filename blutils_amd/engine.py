@@ -154,10 +154,31 @@ class Taxonomy:
             pass
 
 
+def pack_records(tax_row, pident_milli, align_len, acc_rank) -> np.ndarray:
+    """[n, 4] uint32 side records {tax_row, pident_milli, align_len, acc_rank} of the packed layout (ABI v3)."""
+    cols = [np.ascontiguousarray(c) for c in (tax_row, pident_milli, align_len, acc_rank)]
+    cols = [c.view(np.uint32) if c.dtype == np.int32 else c.astype(np.uint32) for c in cols]
+    return np.ascontiguousarray(np.stack(cols, axis=1))
+
+
 def run_consensus_host(tax: Taxonomy, seg_off, bitscore, tax_row, pident, align_len, acc_rank,
-                       strategy: str = "relaxed", pident_milli=None) -> np.ndarray:
+                       strategy: str = "relaxed", pident_milli=None, packed: bool = False) -> np.ndarray:
     """Host buffers in, host records out; the library stages them over PCIe.  tax_row: ENGINE row ids.
-    pident_milli (uint32, perc_identity * 1000) replaces the f64 `pident` column when given (pass pident=None)."""
+    pident_milli (uint32, perc_identity * 1000) replaces the f64 `pident` column when given (pass pident=None);
+    packed=True (needs pident_milli) hands the four non-bit-score columns over as 16-byte records."""
+    if packed:
+        seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
+        bs = np.ascontiguousarray(bitscore, dtype=np.int32)
+        rec = pack_records(tax_row, pident_milli, align_len, acc_rank)
+        nq, nh = len(seg) - 1, int(seg[-1])
+        assert rec.shape == (nh, 4) and rec.ctypes.data % 16 == 0
+        hits = N.Hits(bs.ctypes.data, None, None, None, None, seg.ctypes.data, nh, nq, 0, 0, None, rec.ctypes.data)
+        params = N.RunParams(N.STRATEGY[strategy], 0, None)
+        out = np.zeros(nq, dtype=RESULT_DTYPE)
+        rc = N.lib().blu_consensus_run(tax.handle, C.byref(hits), C.byref(params), out.ctypes.data)
+        if rc != N.BLU_OK:
+            raise N.BluError(rc, "blu_consensus_run")
+        return out
     seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
     bs = np.ascontiguousarray(bitscore, dtype=np.int32)
     tx = np.ascontiguousarray(tax_row)
@@ -174,7 +195,7 @@ def run_consensus_host(tax: Taxonomy, seg_off, bitscore, tax_row, pident, align_
     nh = int(seg[-1])
     assert len(bs) == nh and len(tx) == nh and len(pid if pm is None else pm) == nh and len(aln) == nh and len(ac) == nh
     hits = N.Hits(bs.ctypes.data, tx.ctypes.data, pid.ctypes.data if pm is None else None, aln.ctypes.data, ac.ctypes.data,
-                  seg.ctypes.data, nh, nq, 0, 0, pm.ctypes.data if pm is not None else None)
+                  seg.ctypes.data, nh, nq, 0, 0, pm.ctypes.data if pm is not None else None, None)
     params = N.RunParams(N.STRATEGY[strategy], 0, None)
     out = np.zeros(nq, dtype=RESULT_DTYPE)
     rc = N.lib().blu_consensus_run(tax.handle, C.byref(hits), C.byref(params), out.ctypes.data)
@@ -209,7 +230,7 @@ def run_consensus_multi(taxes: Sequence[Taxonomy], seg_off, bitscore, tax_row, p
     ac = ac.view(np.uint32) if ac.dtype == np.int32 else np.ascontiguousarray(ac, dtype=np.uint32)
     nq, nh = len(seg) - 1, int(seg[-1])
     hits = N.Hits(bs.ctypes.data, tx.ctypes.data, pid.ctypes.data if pm is None else None, aln.ctypes.data, ac.ctypes.data,
-                  seg.ctypes.data, nh, nq, 0, 0, pm.ctypes.data if pm is not None else None)
+                  seg.ctypes.data, nh, nq, 0, 0, pm.ctypes.data if pm is not None else None, None)
     params = N.RunParams(N.STRATEGY[strategy], 0, None)
     out = np.zeros(nq, dtype=RESULT_DTYPE)
     handles = (C.c_void_p * len(taxes))(*[t.handle for t in taxes])
@@ -231,17 +252,27 @@ def run_consensus_device(tax: Taxonomy, hits: dict, out, strategy: str = "relaxe
     nq = hits["seg_off"].numel() - 1
     nh = hits["bitscore"].numel()
     milli = hits.get("pident_milli") is not None
-    for k, dt in (("seg_off", torch.int64), ("bitscore", torch.int32), ("tax_row", torch.int32),
-                  ("pident_milli", torch.int32) if milli else ("pident", torch.float64), ("align_len", torch.int32),
-                  ("acc_rank", torch.int32)):
+    packed = hits.get("packed") is not None
+    if packed:     # 16-byte side records {tax_row, pident_milli, align_len, acc_rank} next to the bit-score column
+        want = (("seg_off", torch.int64), ("bitscore", torch.int32), ("packed", torch.int32))
+    else:
+        want = (("seg_off", torch.int64), ("bitscore", torch.int32), ("tax_row", torch.int32),
+                ("pident_milli", torch.int32) if milli else ("pident", torch.float64), ("align_len", torch.int32),
+                ("acc_rank", torch.int32))
+    for k, dt in want:
         t = hits[k]
         assert t.is_cuda and t.is_contiguous() and t.dtype == dt, (k, t.dtype, t.device)
     assert out.is_cuda and out.is_contiguous() and out.numel() * out.element_size() >= 32 * nq
     if stream is None:
         stream = torch.cuda.current_stream().cuda_stream
-    h = N.Hits(hits["bitscore"].data_ptr(), hits["tax_row"].data_ptr(), None if milli else hits["pident"].data_ptr(),
-               hits["align_len"].data_ptr(), hits["acc_rank"].data_ptr(), hits["seg_off"].data_ptr(), nh, nq, 1, 0,
-               hits["pident_milli"].data_ptr() if milli else None)
+    if packed:
+        assert hits["packed"].numel() == 4 * nh and hits["packed"].data_ptr() % 16 == 0
+        h = N.Hits(hits["bitscore"].data_ptr(), None, None, None, None, hits["seg_off"].data_ptr(), nh, nq, 1, 0, None,
+                   hits["packed"].data_ptr())
+    else:
+        h = N.Hits(hits["bitscore"].data_ptr(), hits["tax_row"].data_ptr(), None if milli else hits["pident"].data_ptr(),
+                   hits["align_len"].data_ptr(), hits["acc_rank"].data_ptr(), hits["seg_off"].data_ptr(), nh, nq, 1, 0,
+                   hits["pident_milli"].data_ptr() if milli else None, None)
     params = N.RunParams(N.STRATEGY[strategy], 0, stream)
     rc = N.lib().blu_consensus_run(tax.handle, C.byref(h), C.byref(params), out.data_ptr())
     if rc != N.BLU_OK:

@@ -249,6 +249,10 @@ class SynthHits:
         """layout "f64": the canonical 24 B/hit columns; "milli": pident as milli-percent uint32, 20 B/hit."""
         d = {"seg_off": self.seg_off, "bitscore": self.bitscore, "tax_row": self.tax_row,
              "align_len": self.align_len, "acc_rank": self.acc_rank}
+        if layout == "packed":   # bit-score column + 16-byte side records {tax_row, pident_milli, align_len, acc_rank}
+            import torch
+            rec = torch.stack([self.tax_row, self.pident_milli, self.align_len, self.acc_rank], dim=1).contiguous().reshape(-1)
+            return {"seg_off": self.seg_off, "bitscore": self.bitscore, "packed": rec}
         if layout == "milli":
             d["pident_milli"] = self.pident_milli
         else:
@@ -260,7 +264,7 @@ class SynthHits:
 
     def algorithmic_bytes(self, layout: str = "f64") -> int:
         """SURVEY §8d / BASELINE.md §3: (24 | 20)·H + 8·(Q+1) + 32·Q — the bytes of the layout actually read."""
-        return (20 if layout == "milli" else 24) * self.n_hits + 8 * (self.n_queries + 1) + 32 * self.n_queries
+        return (24 if layout == "f64" else 20) * self.n_hits + 8 * (self.n_queries + 1) + 32 * self.n_queries
 
 
 def make_hits(tax: SynthTaxonomy, n_queries: int, seed: int, hits_per_query: Optional[int] = 50,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BLU_ABI_VERSION 2u
+#define BLU_ABI_VERSION 3u
 #define BLU_UNMATCHED_TAXID 0xFFFFFFFFu /* hit whose subject_taxid is not in the taxonomy (left join miss, mod.rs:72-76) */
 #define BLU_MAX_DEPTH 64u               /* level_mask is 64 bits wide */
 #define BLU_ROW_BITS 25u                /* engine row id = sorted position | lineage length << 25: at most 2^25 taxids */
@@ -104,7 +104,13 @@ typedef struct blu_hits {
                                   text has at most 3 decimals (BLAST outfmt 6 prints %.3f): k = perc_identity * 1000
                                   as an exact integer.  The engine rebuilds the f64 the reference's parser produces,
                                   the correctly rounded k / 1000, for the few rows that need it.  20 B/hit instead of
-                                  24.  Exactly one of pident / pident_milli is non-NULL. */
+                                  24.  Exactly one of pident / pident_milli / packed is non-NULL. */
+    const uint32_t* packed;    /* [n_hits][4] or NULL (ABI v3).  The four non-bit-score values of a hit side by side,
+                                  16 bytes per hit: {tax_row, pident_milli, align_len, acc_rank}; tax_row, pident,
+                                  pident_milli, align_len and acc_rank are then ignored (may be NULL).  Same 20 B/hit
+                                  as the milli-percent columns, but the engine — which reads those four values for the
+                                  top-scoring rows only — finds a row's values in ONE memory line instead of four.
+                                  16-byte aligned. */
 } blu_hits;
 
 typedef struct blu_run_params {

@@ -453,3 +453,34 @@ def test_lanes_per_query_paths(hits):
     take = np.concatenate([np.arange(l) + 300 * i for i, l in enumerate(lens)])
     ragged = {k: (base[k][take] if k != "seg_off" else seg) for k in base}
     _assert_records_equal(_run_host(t, ragged, "relaxed"), H.columnar(tax, ragged, "custom", "relaxed", H.CUSTOM_16S))
+
+
+def test_packed_layout_gives_identical_records():
+    """ABI v3: the four non-bit-score values of a hit as one 16-byte record next to the bit-score column.  Records must be
+    bit-identical to the column layouts on the streamed widths, the long pass, the worklist kernel, through host and
+    device pointers, and through the chunked / sharded host paths."""
+    import torch
+    tax = synth.make_taxonomy(30000, synth.SEEDS["C5"], deep=True)
+    dh = synth.make_hits(tax, 30000, synth.SEEDS["C5"], None, zipf=(1.1, 1, 3000), device="cuda")
+    t = _engine_tax(tax, "bacteria")
+    dh.tax_row = t.engine_rows(dh.tax_row).contiguous()
+    outs = []
+    for layout in ("milli", "packed"):
+        out = torch.zeros(32 * dh.n_queries, dtype=torch.uint8, device="cuda")
+        engine.run_consensus_device(t, dh.as_dict(layout), out, strategy="cautious")
+        torch.cuda.synchronize()
+        outs.append(engine.records_from_tensor(out))
+    assert outs[0].tobytes() == outs[1].tobytes()
+    # fixed lengths around every width, host pointers
+    for hits_per_query in (7, 20, 30, 50, 100, 200, 400, 600):
+        tax2 = synth.make_taxonomy(3000, 77)
+        d2 = synth.make_hits(tax2, 900, 300 + hits_per_query, hits_per_query, p_unmatched=0.003)
+        h2 = d2.numpy()
+        t2 = _engine_tax(tax2, "custom", H.CUSTOM_16S)
+        rows = t2.engine_rows(h2["tax_row"])
+        milli = d2.pident_milli.numpy()
+        a = engine.run_consensus_host(t2, h2["seg_off"], h2["bitscore"], rows, None, h2["align_len"], h2["acc_rank"], "relaxed", pident_milli=milli)
+        b = engine.run_consensus_host(t2, h2["seg_off"], h2["bitscore"], rows, None, h2["align_len"], h2["acc_rank"], "relaxed", pident_milli=milli,
+                                      packed=True)
+        assert a.tobytes() == b.tobytes(), hits_per_query
+        _assert_records_equal(b, H.columnar(tax2, h2, "custom", "relaxed", H.CUSTOM_16S))
