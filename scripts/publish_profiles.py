@@ -5,7 +5,7 @@ traffic figure bench.py quotes: traffic = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> by
 is a 128-byte request: TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ)."""
 import json, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-config = sys.argv[2] if len(sys.argv) > 2 else "C3-milli"   # key = config, "-milli" suffix for the 20 B/hit layout
+config = sys.argv[2] if len(sys.argv) > 2 else "C3-packed"   # key = config, "-milli" suffix for the 20 B/hit layout
 src = f"gpurun_out/profiles_{tag}"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(f"{src}/kernel_stats_blu.csv", f"profiles/{tag}_kernel_stats.csv")
