@@ -625,7 +625,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             const uint32_t rows = L.seg[lane].y;                    // this lane's query (0: empty, too long, or outside the span)
             const uint32_t longest = wave_max_u32(rows > SHORT_SEG ? 0u : rows);   // longest streamed segment of the task
             if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>(), false);   // the C3 shape, specialised
-            else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u), longest >= 25u);
+            else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u), longest >= (PACKED ? 9u : 25u));   // two-stage steps: measured break-even (packed records: 10 hits -2.5 %, 20 hits -17 %; columns: 20 hits +3 %, 30 hits -6 %)
             const uint64_t long_mask = __ballot(rows > SHORT_SEG);
             if (long_mask) phase1_long(long_mask);                // after the streamed pass: it overwrites their (empty) list heads
         }
