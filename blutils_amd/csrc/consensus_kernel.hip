@@ -4,14 +4,15 @@
 // find_single_query_consensus.rs:17-173, find_multi_taxa_consensus.rs:22-217,
 // build_blast_consensus_identity.rs:9-105 (restated in SURVEY §3.3).
 //
-// Kernel A  blu_consensus_stream_kernel — the streaming path (segments <= 512 hits).
+// Kernel A  blu_consensus_stream_kernel — segments of up to 512 hits.
 //   A wave task is 64 consecutive queries; the waves of a block take consecutive tasks.
-//   phase 1 (lane = 4 consecutive hit rows; segments up to 128 rows streamed with 4 .. 32 lanes per query, chosen per
-//     task; segments of 129 .. 512 rows in a sparse long pass: bit-scores first, other columns for top rows only):
-//     16-byte buffer loads of the five SoA columns, M = max bit_score by a 16-lane
-//     DPP row reduction, top rows ranked by a DPP row scan and compacted in file
-//     order into a per-wave LDS list (row id, align_len, accession rank, position,
-//     pident).  The row id carries the lineage length: no taxonomy lookup here.
+//   phase 1 (lane = 4 consecutive hit rows): segments of up to 128 rows in steps of 64 lanes with 4 .. 32 lanes per
+//     query (chosen per task); segments of 129 .. 512 rows in a long pass of two 256-row slots per step.  A step
+//     loads the bit-scores (16-byte buffer loads), finds the top score by a DPP reduction over the query's lanes and
+//     ranks the top rows by a DPP scan; the other four values of a hit (taxonomy row, perc_identity, align_length,
+//     accession rank — 16-byte side records in the packed layout, four columns otherwise) are then loaded for the
+//     top rows only, and compacted in file order into a per-wave LDS list.  (Tasks of very short segments load
+//     everything at once.)  The row id carries the lineage length: no taxonomy lookup here.
 //   phase 2a (lane = query, LDS only): parse errors, reference row by the stable-sort
 //     rule, shortest lineage, group-max pident, span [lo, hi] in sorted lineage order.
 //   phase 2c (lane = query): one 128-byte line of the reference row gives, per level,
@@ -25,9 +26,8 @@
 // Kernel B  blu_consensus_long_kernel — worklist queries, one wave per query,
 //   chunked passes over the segment (any length), wave-parallel finalisation.
 //
-// Integer/compare work only: no MFMA.  The roofline is the HBM stream of the
-// five columns (20 B/hit with the milli-percent perc_identity, 24 B/hit with f64)
-// + 8 B offsets + 32 B record per query.
+// Integer/compare work only: no MFMA.  HBM-bound: every bit-score is read (4 B/hit), the other 16 B/hit for top rows
+// only, one reference-row line and one 32-byte record per query.
 // BLU_EXP_* macros are timing-only experiment hooks (scripts/build_variants.sh);
 // the product build defines none of them.
 #include <hip/hip_runtime.h>
