@@ -781,13 +781,22 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                         }
                     }
                 };
-                {
-                    uint4 c[4];
+                uint4 c[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) c[k] = codes4[k];
+                for (int k = 0; k < 4; ++k) c[k] = codes4[k];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { level(4 * k, c[k].x); level(4 * k + 1, c[k].y); level(4 * k + 2, c[k].z); level(4 * k + 3, c[k].w); }
-                }
+                for (int k = 0; k < 4; ++k) { level(4 * k, c[k].x); level(4 * k + 1, c[k].y); level(4 * k + 2, c[k].z); level(4 * k + 3, c[k].w); }
+                // codes word of level j again (rank codes of the reached / allowed levels): from the registers for the first
+                // 16 levels — going back to memory for them put a third dependent lookup on the task's critical path
+                const uint32_t cw[16] = {c[0].x, c[0].y, c[0].z, c[0].w, c[1].x, c[1].y, c[1].z, c[1].w,
+                                         c[2].x, c[2].y, c[2].z, c[2].w, c[3].x, c[3].y, c[3].z, c[3].w};
+                auto code_of = [&](uint32_t j) {
+                    uint32_t v = 0;
+                    if (j >= 16) v = codes[j];
+#pragma unroll
+                    for (uint32_t i = 0; i < 16; ++i) v = (j == i) ? cw[i] : v;
+                    return v;
+                };
                 for (uint32_t k = 4; 4 * k < len_ref; ++k) {   // lineages deeper than 16 levels
                     const uint4 x = codes4[k];
                     level(4 * k, x.x); level(4 * k + 1, x.y); level(4 * k + 2, x.z); level(4 * k + 3, x.w);
@@ -807,17 +816,17 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     if (!A) pack_status(ra, rb, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, row0 + r_pos);   // find_single_query_consensus.rs:113-119
                     else {
                         const uint32_t last = (uint32_t)last_lane(A);
-                        pack_result(ra, rb, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, packed_rank(codes[last]), BLU_NONE_U16,
+                        pack_result(ra, rb, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, packed_rank(code_of(last)), BLU_NONE_U16,
                                      node_of(last), row0 + r_pos, A, ident);
                     }
                 } else {
                     const uint32_t last = A ? (uint32_t)last_lane(A) : b;          // .last().unwrap_or(taxonomy[bean_index])
                     uint32_t flags = agree ? BLU_FLAG_AGREE : 0u, mar_code = BLU_NONE_U16;
                     if (mar_level != BLU_NONE_U8) {
-                        mar_code = packed_mar(codes[mar_level]);
-                        if (mar_code != packed_rank(codes[b])) flags |= BLU_FLAG_MUTATED;   // bean.reached_rank != allowed_rank (:35-37)
+                        mar_code = packed_mar(code_of(mar_level));
+                        if (mar_code != packed_rank(code_of(b))) flags |= BLU_FLAG_MUTATED;   // bean.reached_rank != allowed_rank (:35-37)
                     }
-                    pack_result(ra, rb, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, packed_rank(codes[last]), mar_code,
+                    pack_result(ra, rb, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, packed_rank(code_of(last)), mar_code,
                                  node_of(last), row0 + r_pos, A, ident);
                 }
             }
