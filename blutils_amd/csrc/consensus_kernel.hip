@@ -20,7 +20,7 @@
 //     span; a range minimum over the adjacent-row LCP array for wide spans) and the
 //     node ids; per-level cutoff ids (values in LDS) and rank codes come from the
 //     table row of the lineage's shape; cutoff tests; record.
-//   Records are staged in LDS and leave as one write-through burst per block.
+//   Records are staged in LDS and leave as one write-through 2 KiB run per wave task.
 //   Queries with more than 512 hits, or whose top group does not fit the LDS
 //   list, are appended to a worklist.
 // Kernel B  blu_consensus_long_kernel — worklist queries, one wave per query,
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     WaveLds& L = s_lds[wib];
     const uint64_t n_tasks = (h.n_queries + WAVE - 1) / WAVE;
-#ifdef BLU_WAVE_RECORDS
+#ifndef BLU_BLOCK_RECORDS
     const uint64_t wave = (uint64_t)blockIdx.x * WAVES_A + wib;
     const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_A;
 
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         // write-through + non-temporal (sc1 nt): a record is written once and never read by the GPU; letting the
         // lines sit dirty in L2 until the read stream evicts them one by one costs ~2x more HBM time (probe:
         // scripts/probe/pattern_probe.hip store modes 1 vs 18)
-#ifdef BLU_WAVE_RECORDS
+#ifndef BLU_BLOCK_RECORDS
         const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + q0), 0, nq * 32u, 0x00020000);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
