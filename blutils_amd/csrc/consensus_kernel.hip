@@ -214,9 +214,9 @@ __device__ __forceinline__ uint32_t shared_levels(const TaxDev& t, uint32_t lo, 
 // ===============================================================================
 // Kernel A
 // ===============================================================================
-struct Entry {            // one top-group row in LDS, 24 bytes
-    uint32_t id, aln, acc, pq;    // id = engine row id (sorted position | length << BLU_ROW_BITS); pq = position in the segment
-    uint32_t p0, p1;              // pident: f64 bits (lo, hi), or the milli-percent integer in p0
+struct Entry {            // one top-group row in LDS, 24 bytes; the first 16 = a side record of the packed layout as it is
+    uint32_t id, p0, aln, acc;    // id = engine row id (sorted position | length << BLU_ROW_BITS); p0: milli-percent pident, or the low f64 word
+    uint32_t pq, p1;              // pq = position in the segment; p1 = high f64 word (f64 layout only)
 };
 template <bool PID32> struct PidKey { typedef double type; };
 template <> struct PidKey<true> { typedef uint32_t type; };
@@ -378,12 +378,17 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             R.vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, vo, 0, STREAM_AUX);
         };
         // row r of the lane as a list entry
-        auto make_entry = [&](const StepRegs& R, const int r, const uint32_t pos) {
-            Entry e;
-            if (PACKED) {
+        auto put_entry = [&](const uint32_t idx, const StepRegs& R, const int r, const uint32_t pos) {
+            if (PACKED) {   // the loaded record goes to the list as one 16-byte write, the position after it
                 const u32x4 rec = r == 0 ? R.vtax : (r == 1 ? R.vp01 : (r == 2 ? R.valn : R.vacc));
-                e.id = rec.x; e.p0 = rec.y; e.p1 = 0u; e.aln = rec.z; e.acc = rec.w;
-            } else {
+                uint32_t* dst = reinterpret_cast<uint32_t*>(&L.list[idx]);
+                *reinterpret_cast<u32x2*>(dst) = u32x2{rec.x, rec.y};          // (24-byte entries are 8-byte aligned)
+                *reinterpret_cast<u32x2*>(dst + 2) = u32x2{rec.z, rec.w};
+                dst[4] = pos;
+                return;
+            }
+            Entry e;
+            {
                 const uint32_t xt[4] = {R.vtax.x, R.vtax.y, R.vtax.z, R.vtax.w}, xa[4] = {R.valn.x, R.valn.y, R.valn.z, R.valn.w};
                 const uint32_t xc[4] = {R.vacc.x, R.vacc.y, R.vacc.z, R.vacc.w};
                 const uint32_t xm[4] = {R.vp01.x, R.vp01.y, R.vp01.z, R.vp01.w};   // milli-percent column
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 e.p1 = PID32 ? 0u : xhi[r];
             }
             e.pq = pos;
-            return e;
+            L.list[idx] = e;
         };
         auto phase1 = [&](const auto lpq, const bool sparse8) {   // wave-uniform width: a constant for 16 lanes, a variable otherwise
         const uint32_t LPQ = lpq;
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
 #else
                 if (T.fits && ((T.tmask >> r) & 1u)) {
 #endif
-                    L.list[idx] = make_entry(R, r, sub4 + r);   // the row id carries the lineage length: phase 1 touches no taxonomy table
+                    put_entry(idx, R, r, sub4 + r);   // the row id carries the lineage length: phase 1 touches no taxonomy table
                     ++idx;
                 }
             }
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             if ((tmask[hf] >> r) & 1u) {
-                                L.list[idx] = make_entry(S, r, ro[hf] + sub4 + r);
+                                put_entry(idx, S, r, ro[hf] + sub4 + r);
                                 ++idx;
                             }
                         }
