@@ -400,6 +400,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             e.pq = pos;
             L.list[idx] = e;
         };
+        uint32_t stop_q = WAVE;      // first query index phase 1 did not get to in this round (the list was full), or 64
+        uint32_t first_q = 0;        // first pending query of the round
         auto phase1 = [&](const auto lpq, const bool sparse8) {   // wave-uniform width: a constant for 16 lanes, a variable otherwise
         const uint32_t LPQ = lpq;
         const uint32_t QPS = WAVE / LPQ;                          // queries per step
@@ -494,13 +496,15 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             // bit-scores of iteration i+1 are requested, so a wave pays one exposed round trip per iteration, not two
             StepRegs R[BLU_STEP_SETS];
             StepTops T[BLU_STEP_SETS];
+            const uint32_t qb0 = first_q / (QPS * BLU_STEP_SETS) * (QPS * BLU_STEP_SETS);   // (queries before it are done)
 #pragma unroll
-            for (int u = 0; u < BLU_STEP_SETS; ++u) issue(QPS * u, R[u]);
-            for (uint32_t qb = 0; qb < nq; qb += QPS * BLU_STEP_SETS) {
+            for (int u = 0; u < BLU_STEP_SETS; ++u) issue(qb0 + QPS * u, R[u]);
+            for (uint32_t qb = qb0; qb < nq; qb += QPS * BLU_STEP_SETS) {
+                bool all_fit = true;
 #pragma unroll
-                for (int u = 0; u < BLU_STEP_SETS; ++u) { asm volatile("" ::"v"(R[u].vbs)); tops(R[u], T[u]); }
+                for (int u = 0; u < BLU_STEP_SETS; ++u) { asm volatile("" ::"v"(R[u].vbs)); tops(R[u], T[u]); all_fit &= T[u].fits; }
                 StepRegs N[BLU_STEP_SETS];
-                const bool more = qb + QPS * BLU_STEP_SETS < nq;
+                const bool more = all_fit && qb + QPS * BLU_STEP_SETS < nq;
                 if (more) {
 #pragma unroll
                     for (int u = 0; u < BLU_STEP_SETS; ++u) issue(qb + QPS * BLU_STEP_SETS + QPS * u, N[u]);
@@ -510,21 +514,23 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     asm volatile("" ::"v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc));
                     emit(R[u], T[u]);
                 }
+                if (!all_fit) { stop_q = qb + QPS * BLU_STEP_SETS; break; }   // the list is full: the rest of the task in the next round
 #pragma unroll
                 for (int u = 0; u < BLU_STEP_SETS; ++u) { asm volatile("" ::"v"(N[u].vbs)); R[u].vbs = N[u].vbs; R[u].left = N[u].left; R[u].qi = N[u].qi; }
             }
             return;
         }
 #endif
-        for (uint32_t qb = 0; qb < nq; qb += QPS * BLU_STEP_SETS) {
+        for (uint32_t qb = first_q / (QPS * BLU_STEP_SETS) * (QPS * BLU_STEP_SETS); qb < nq; qb += QPS * BLU_STEP_SETS) {
             StepRegs R[BLU_STEP_SETS];
             StepTops T[BLU_STEP_SETS];
+            bool all_fit = true;
 #pragma unroll
             for (int u = 0; u < BLU_STEP_SETS; ++u) issue(qb + QPS * u, R[u]);
 #ifndef BLU_EXP_NOREDUCE
             if (sparse) {
 #pragma unroll
-                for (int u = 0; u < BLU_STEP_SETS; ++u) { asm volatile("" ::"v"(R[u].vbs)); tops(R[u], T[u]); }
+                for (int u = 0; u < BLU_STEP_SETS; ++u) { asm volatile("" ::"v"(R[u].vbs)); tops(R[u], T[u]); all_fit &= T[u].fits; }
 #pragma unroll
                 for (int u = 0; u < BLU_STEP_SETS; ++u) {
                     asm volatile("" ::"v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc));
@@ -536,10 +542,12 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     // every loaded register is read here on every path (otherwise hipcc parks a vmcnt(0) at the loop head)
                     asm volatile("" ::"v"(R[u].vbs), "v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc));
                     tops(R[u], T[u]);
+                    all_fit &= T[u].fits;
                     emit(R[u], T[u]);
                 }
             }
 #endif
+            if (!all_fit) { stop_q = qb + QPS * BLU_STEP_SETS; break; }   // the list is full: the rest of the task in the next round
         }
         };
         // Segments of 129..512 rows: a step holds two 256-row slots — two queries, or the two halves of one query longer
@@ -607,7 +615,12 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                         if (qs[1] < 64u) L.meta[qs[1]] = fits ? ((fill + tot[0]) | (tot[1] << 16)) : META_SLOW;
                     }
                 }
-                if (fits) {
+                if (!fits) {                                      // the list is full: the remaining long queries in the next round
+                    uint64_t rest = long_mask;
+                    while (rest) { const uint32_t qn = (uint32_t)__builtin_ctzll(rest); rest &= rest - 1; if (lane == 0) L.meta[qn] = META_SLOW; }
+                    break;
+                }
+                {
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         if (tot[hf] == 0) continue;                       // wave-uniform: no top row in this slot
@@ -626,20 +639,42 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 }
             }
         };
+        // per-lane (= per-query) results of phase 2a
+        // mode: 0 multi, 2 single, 3 finished (empty / error / handed to the worklist)
+        const uint64_t q = q0 + (uint32_t)lane;
+        const uint32_t row0 = (uint32_t)my_off;
+        // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
+        uint32_t mode = 3, r_len = 0, r_row = 0, r_pos = 0, r_hdr = 0, minlen = 0, d = 0, rec_kind = 0, g_lo = 0, g_hi = 0;
+        typedef typename PidKey<PID32>::type PK;
+        PK r_pid = 0, max_pid = 0;   // fold(0.0, max): find_multi_taxa_consensus.rs:182-185
+        uint4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+        // Phase 1 and phase 2a run in ROUNDS: a round compacts the top rows of as many pending queries as the LDS list holds
+        // (the steps that do not fit are marked and come again), phase 2a reduces them, the list is reused.  With small
+        // top groups (the usual case) everything fits and there is one round; with many ties per query — identical
+        // database sequences — a task takes a few rounds instead of sending its queries to the worklist kernel.
+        bool pend = (uint32_t)lane < nq, exp_skip = false;
+        uint32_t pend_before = WAVE + 1;
+        for (;;) {
+        fill = 0;
+        stop_q = WAVE;
         {
-            const uint32_t rows = L.seg[lane].y;                    // this lane's query (0: empty, too long, or outside the span)
+            const uint32_t rows = L.seg[lane].y;                    // this lane's query (0: empty, done, too long, or outside the span)
+            const uint64_t live = __ballot(rows != 0u);
+            first_q = live ? (uint32_t)__builtin_ctzll(live) : 0u;
             const uint32_t longest = wave_max_u32(rows > SHORT_SEG ? 0u : rows);   // longest streamed segment of the task
             if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>(), false);   // the C3 shape, specialised
             else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u), longest >= (PACKED ? 9u : 25u));   // two-stage steps: measured break-even (packed records: 10 hits -2.5 %, 20 hits -17 %; columns: 20 hits +3 %, 30 hits -6 %)
+            // queries phase 1 did not get to (the list filled up): marked for the next round, long ones included
+            if (stop_q < WAVE && rows != 0u && ((uint32_t)lane >= stop_q || rows > SHORT_SEG)) L.meta[lane] = META_SLOW;
             const uint64_t long_mask = __ballot(rows > SHORT_SEG);
-            if (long_mask) phase1_long(long_mask);                // after the streamed pass: it overwrites their (empty) list heads
+            if (long_mask && stop_q == WAVE) phase1_long(long_mask);   // after the streamed pass: it overwrites their (empty) list heads
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
 #ifdef BLU_EXP_NOSTORE
-        continue;
+        exp_skip = true; break;
 #endif
 #ifdef BLU_EXP_P1ONLY
         {
@@ -655,22 +690,16 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             for (int half = 0; half < 2; ++half) { const uint32_t c = (uint32_t)lane + 64u * half; if ((c >> 1) < nq) dst[c] = rec[c]; }
             __builtin_amdgcn_wave_barrier();
         }
-        continue;
+        exp_skip = true; break;
 #endif
         // ---------------- phase 2a: lane = query, LDS only ----------------
-        // mode: 0 multi, 2 single, 3 finished (empty / error / handed to the worklist)
-        const uint64_t q = q0 + (uint32_t)lane;
-        const uint32_t row0 = (uint32_t)my_off;
-        // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
-        uint32_t mode = 3, r_len = 0, r_row = 0, r_pos = 0, r_hdr = 0, minlen = 0, d = 0, rec_kind = 0, g_lo = 0, g_hi = 0;
-        typedef typename PidKey<PID32>::type PK;
-        PK r_pid = 0, max_pid = 0;   // fold(0.0, max): find_multi_taxa_consensus.rs:182-185
-        uint4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
-        if ((uint32_t)lane < nq) {
+        if (pend) {
             const uint64_t nrows = my_end - my_off;
             const uint32_t m = L.meta[lane];
+            bool done = true;
             if (nrows == 0) { pack_status(ra, rb, BLU_ST_NO_HITS, 0xFFFFFFFFu); rec_kind = 1; }   // mod.rs:107-113
-            else if (nrows > MAX_TASK_SEG || !in_span || (m & META_SLOW)) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
+            else if (nrows > MAX_TASK_SEG || !in_span) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
+            else if (m & META_SLOW) done = false;   // its step did not fit the list this round: again in the next one
             else {
                 const uint32_t first = m & 0xFFFF, k = (m >> 16) & 0x3FF;
                 // parse errors first, in file order (find_single_query_consensus.rs:51-64), then NaN pident
@@ -715,7 +744,17 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     g_lo = lo; g_hi = hi;    // span of the group in sorted order: phase 2c turns it into the shared levels
                 }
             }
+            if (done) { pend = false; L.seg[lane].y = 0u; }   // later rounds skip it
         }
+        const uint32_t pend_now = (uint32_t)__builtin_popcountll(__ballot(pend));
+        if (pend_now == 0 || pend_now >= pend_before) break;      // all reduced, or a round without progress
+        pend_before = pend_now;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (exp_skip) continue;
+        if (pend) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;   // a single step larger than the whole list
 
         // ---------------- phase 2c: lane = query, cutoff tests and the record ----------------
 #ifdef BLU_EXP_SKIP_2C

@@ -484,3 +484,24 @@ def test_packed_layout_gives_identical_records():
                                       packed=True)
         assert a.tobytes() == b.tobytes(), hits_per_query
         _assert_records_equal(b, H.columnar(tax2, h2, "custom", "relaxed", H.CUSTOM_16S))
+
+
+@pytest.mark.parametrize("group", [3, 6, 14, 30, 50])
+def test_many_ties_take_rounds_not_the_worklist(group):
+    """Top groups of `group` rows per query (identical database sequences tie on bit-score): the 64 queries of a wave
+    task no longer fit its LDS list at once, so phase 1 / 2a run in rounds.  Same records as the oracle."""
+    tax = synth.make_taxonomy(5000, 31)
+    dh = synth.make_hits(tax, 2500, 32 + group, 50)
+    h = dh.numpy()
+    bs = h["bitscore"].reshape(-1, 50).copy()
+    bs[:, :group] = bs.max(axis=1, keepdims=True)
+    h["bitscore"] = bs.reshape(-1)
+    t = _engine_tax(tax, "custom", H.CUSTOM_16S)
+    rows = t.engine_rows(h["tax_row"])
+    for strategy in ("relaxed", "cautious"):
+        exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S)
+        got = _run_host(t, h, strategy)
+        _assert_records_equal(got, exp)
+        pk = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy,
+                                       pident_milli=dh.pident_milli.numpy(), packed=True)
+        assert pk.tobytes() == exp.tobytes()
