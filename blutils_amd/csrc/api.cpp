@@ -214,6 +214,7 @@ int blu_consensus_run_multi(const blu_taxonomy* const* taxes, uint32_t n, const 
     if (!out || !hits->seg_off) { set_error("null output or seg_off"); return BLU_ERR_INVALID_ARG; }
     for (uint64_t q = 0; q < hits->n_queries; ++q)
         if (hits->seg_off[q] > hits->seg_off[q + 1]) { set_error("seg_off must be ascending for a sharded run"); return BLU_ERR_INVALID_ARG; }
+    if (hits->seg_off[hits->n_queries] > hits->n_hits) { set_error("seg_off runs past n_hits"); return BLU_ERR_INVALID_ARG; }
     std::vector<uint64_t> bounds(n + 1);
     int rc = blu_shard_ranges(hits->seg_off, hits->n_queries, n, bounds.data());
     if (rc != BLU_OK) return rc;
