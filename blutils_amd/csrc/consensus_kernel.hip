@@ -105,7 +105,9 @@ __device__ __forceinline__ uint64_t rl_u64(uint64_t v, int lane) {
     return (uint64_t)(uint32_t)rl((int)(uint32_t)v, lane) | ((uint64_t)(uint32_t)rl((int)(uint32_t)(v >> 32), lane) << 32);
 }
 __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
-    return (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)v) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
+    // (the builtin returns int: without the casts a low word with bit 31 set sign-extends into the high word)
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32);
 }
 
 // ---- record store -------------------------------------------------------------

@@ -70,3 +70,59 @@ def test_c3_full_size_properties():
                "acc_rank": dh.acc_rank[r0:r1].cpu().numpy()}
         o = H.columnar(tax, sub, "custom", "relaxed", H.CUSTOM_16S, threads=8)
         assert shard.rebase_records(o, r0).tobytes() == whole[q0:q0 + 2500].tobytes()
+
+
+@pytest.mark.parametrize("layout", ["packed", "f64"])
+def test_table_near_the_row_limit_is_periodic(layout):
+    """The ABI's maximum: just under 2^32 - 1 hit rows in one call (include/blu_consensus.h), row offsets far past
+    2^31 and byte offsets past 64 GiB.  The table is one 100 k-query block (Zipf 1..3000 hits per query, deep lineages:
+    streamed, long-pass and worklist segments) repeated back to back, so the records must repeat with it —
+    reference rows shifted by the block's row count — and the first block is checked against the oracle."""
+    import torch
+    free_b, _ = torch.cuda.mem_get_info()
+    per_row = 20 if layout == "packed" else 24
+    if free_b < (1 << 32) * (per_row + 4) + (32 << 30):
+        pytest.skip("needs a device with > 130 GB free")
+    tax = synth.make_taxonomy(30000, synth.SEEDS["C5"], deep=True)
+    t = engine.Taxonomy(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, taxon="bacteria", device=0)
+    dh = synth.make_hits(tax, 100_000, synth.SEEDS["C5"], None, zipf=(1.1, 1, 3000), device="cuda")
+    Q0, H0 = dh.n_queries, dh.n_hits
+    desc_rows = dh.tax_row.clone()
+    dh.tax_row = t.engine_rows(desc_rows).contiguous()
+    base = dh.as_dict(layout)
+    k = ((1 << 32) - 2) // H0
+    Hn, Q = k * H0, k * Q0
+    assert (1 << 32) - 2 - H0 < Hn < (1 << 32) - 1
+    big = {}
+    for name, col in base.items():
+        if name == "seg_off":
+            seg = (col[:-1].to(torch.int64)[None, :] + (torch.arange(k, device="cuda", dtype=torch.int64) * H0)[:, None]).reshape(-1)
+            big[name] = torch.cat([seg, torch.tensor([Hn], device="cuda", dtype=torch.int64)])
+        else:
+            big[name] = col.repeat(k)
+    torch.cuda.synchronize()
+    print(f"[near-limit] {layout}: {k} blocks of {Q0} queries / {H0} rows = {Q} queries / {Hn} rows", flush=True)
+    assert int(big["seg_off"][-1]) == Hn and big["bitscore"].numel() == Hn
+    out = torch.zeros(32 * Q, dtype=torch.uint8, device="cuda")
+    engine.run_consensus_device(t, big, out, strategy="relaxed")
+    torch.cuda.synchronize()
+    print("[near-limit] kernels done", flush=True)
+    w = out.view(torch.int32).view(k, Q0, 8)                       # word 3 of a record = ref_row
+    first = w[0]
+    other = torch.ones(8, dtype=torch.bool, device="cuda")
+    other[3] = False
+    assert bool((w[:, :, other] == first[None, :, other]).all())
+    has = first[:, 3] != -1
+    ref = w[:, :, 3].to(torch.int64) & 0xFFFFFFFF
+    shift = (torch.arange(k, device="cuda", dtype=torch.int64) * H0)[:, None]
+    assert bool(((ref - shift)[:, has] == (first[:, 3].to(torch.int64) & 0xFFFFFFFF)[None, has]).all())
+    assert bool((w[:, ~has, 3] == -1).all())
+    print("[near-limit] periodic", flush=True)
+    # the block itself against the oracle
+    got = engine.records_from_tensor(out[:32 * Q0])
+    sub = {"seg_off": base["seg_off"].cpu().numpy(), "bitscore": dh.bitscore.cpu().numpy(), "tax_row": desc_rows.cpu().numpy(),
+           "pident": dh.pident.cpu().numpy(), "align_len": dh.align_len.cpu().numpy(), "acc_rank": dh.acc_rank.cpu().numpy()}
+    exp = H.columnar(tax, sub, "bacteria", "relaxed", None, threads=8)
+    assert got.tobytes() == exp.tobytes()
+    st = got["status"]
+    assert (st <= 1).sum() > 0.5 * Q0
