@@ -126,3 +126,70 @@ def test_table_near_the_row_limit_is_periodic(layout):
     assert got.tobytes() == exp.tobytes()
     st = got["status"]
     assert (st <= 1).sum() > 0.5 * Q0
+
+
+def test_one_segment_longer_than_2_31_rows():
+    """A single query of 2^31 + 4096 rows between two ordinary ones (the worklist kernel walks it in 2^28-row spans).
+    Only the top bit-score group matters, so the record must equal the oracle's for the nine top rows alone, with the
+    reference row mapped back to where that row sits in the giant segment — first row, both sides of a span boundary,
+    both sides of 2^31, last row.  Second run: the top row past 2^31 has an unmatched taxid (status 16 at that row)."""
+    import torch
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < (80 << 30):
+        pytest.skip("needs a device with > 80 GB free")
+    tax = synth.make_taxonomy(30000, synth.SEEDS["C5"], deep=True)
+    t = engine.Taxonomy(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, taxon="bacteria", device=0)
+    dh = synth.make_hits(tax, 2000, synth.SEEDS["C5"], 10, device="cuda", p_unmatched=0.0)
+    desc = dh.tax_row.clone()
+    dh.tax_row = t.engine_rows(desc).contiguous()
+    base = dh.as_dict("packed")
+    rec0 = base["packed"].view(-1, 4)                               # 20 000 side records
+    n_big = (1 << 31) + 4096
+    P = torch.tensor([0, 5, (1 << 28) - 1, 1 << 28, (1 << 28) + 7, (1 << 31) - 1, 1 << 31, (1 << 31) + 3, n_big - 1], device="cuda")
+    pre, post = 10, 10                                              # query 0 = rows 0..9 of the base, query 2 = rows 10..19
+    Hn = pre + n_big + post
+    bs = torch.full((Hn,), 100, dtype=torch.int32, device="cuda")
+    bs[:pre] = dh.bitscore[:pre]
+    bs[pre + n_big:] = dh.bitscore[10:20]
+    bs[pre + P] = 200
+    reps = (Hn + rec0.shape[0] - 1) // rec0.shape[0]
+    rec = rec0.repeat(reps, 1)[:Hn].contiguous()
+    rec[:pre] = rec0[:pre]
+    rec[pre + n_big:] = rec0[10:20]
+    top_src = torch.arange(20, 29, device="cuda")                   # the nine top rows: rows of base query 2 (one neighbourhood)
+    rec[pre + P] = rec0[top_src]
+    seg = torch.tensor([0, pre, pre + n_big, Hn], dtype=torch.int64, device="cuda")
+
+    def tiny(unmatched_at=None):
+        src = top_src.cpu().numpy()
+        rows = desc.cpu().numpy()[src].copy()
+        if unmatched_at is not None:
+            rows[unmatched_at] = -1
+        sub = {"seg_off": np.array([0, 9], dtype=np.int64), "bitscore": np.full(9, 200, dtype=np.int32), "tax_row": rows,
+               "pident": dh.pident.cpu().numpy()[src], "align_len": dh.align_len.cpu().numpy()[src],
+               "acc_rank": dh.acc_rank.cpu().numpy()[src]}
+        return H.columnar(tax, sub, "bacteria", "relaxed", None, threads=1)[0]
+
+    def run():
+        out = torch.zeros(32 * 3, dtype=torch.uint8, device="cuda")
+        engine.run_consensus_device(t, {"seg_off": seg, "bitscore": bs, "packed": rec.view(-1)}, out, strategy="relaxed")
+        torch.cuda.synchronize()
+        return engine.records_from_tensor(out)
+
+    Pn = P.cpu().numpy()
+    for unmatched_at in (None, 7):
+        if unmatched_at is not None:
+            rec[pre + P[unmatched_at], 0] = -1                       # BLU_UNMATCHED_TAXID
+        got = run()
+        exp = tiny(unmatched_at).copy()
+        assert exp["status"] == (0 if unmatched_at is None else 16)
+        exp["ref_row"] = np.uint32(pre + Pn[int(exp["ref_row"])])
+        assert got[1].tobytes() == exp.tobytes()
+        # the neighbours are ordinary queries
+        for qi, (a, b) in ((0, (0, 10)), (2, (10, 20))):
+            sub = {"seg_off": np.array([0, 10], dtype=np.int64), "bitscore": dh.bitscore[a:b].cpu().numpy(), "tax_row": desc[a:b].cpu().numpy(),
+                   "pident": dh.pident[a:b].cpu().numpy(), "align_len": dh.align_len[a:b].cpu().numpy(), "acc_rank": dh.acc_rank[a:b].cpu().numpy()}
+            e = H.columnar(tax, sub, "bacteria", "relaxed", None, threads=1)[0].copy()
+            if e["ref_row"] != 0xFFFFFFFF:
+                e["ref_row"] = np.uint32(int(e["ref_row"]) + (0 if qi == 0 else pre + n_big))
+            assert got[qi].tobytes() == e.tobytes()
