@@ -434,14 +434,15 @@ def test_host_table_staged_in_chunks(monkeypatch):
     monkeypatch.delenv("BLU_STAGE_ROWS")
 
 
-@pytest.mark.parametrize("hits", [4, 16, 17, 32, 33, 64, 65, 128, 129, 256, 257])
+@pytest.mark.parametrize("hits", [4, 16, 17, 32, 33, 64, 65, 128, 129, 256, 257, 512, 513, 1024, 1025])
 def test_lanes_per_query_paths(hits):
-    """The stream kernel gives a query 4, 8, 16, 32 or 64 lanes depending on the task's longest segment (<= 16 / 32 / 64 /
-    128 / 256 rows; longer segments go to the worklist kernel): uniform tables on both sides of each boundary, and one
-    ragged table mixing them, against the oracle."""
+    """The stream kernel gives a query 4, 8, 16 or 32 lanes depending on the task's longest streamed segment (<= 16 / 32 /
+    64 / 128 rows), takes 129..512-row segments in its long pass (256-row slots) and leaves longer ones to the worklist
+    kernel (1024 rows per round trip): uniform tables on both sides of each boundary, and one ragged table mixing them,
+    against the oracle."""
     tax = synth.make_taxonomy(4000, synth.SEEDS["C2"])
     t = _engine_tax(tax, "custom", H.CUSTOM_16S)
-    h = synth.make_hits(tax, 3000 if hits <= 64 else 700, 100 + hits, hits, p_unmatched=0.003).numpy()
+    h = synth.make_hits(tax, 3000 if hits <= 64 else (700 if hits <= 257 else 300), 100 + hits, hits, p_unmatched=0.003).numpy()
     for strategy in ("relaxed", "cautious"):
         _assert_records_equal(_run_host(t, h, strategy), H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S))
     # ragged: runs of 64 queries each capped at 16 / 32 / 64 / 128 / 256 / 300 rows, carved out of a 300-hit table
