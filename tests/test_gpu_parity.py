@@ -506,3 +506,37 @@ def test_many_ties_take_rounds_not_the_worklist(group):
         pk = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy,
                                        pident_milli=dh.pident_milli.numpy(), packed=True)
         assert pk.tobytes() == exp.tobytes()
+
+
+@pytest.mark.parametrize("hits", [10, 50, 300, 700])
+def test_extreme_column_values(hits):
+    """Values no BLAST run writes but the ABI's types admit: bit-scores at INT32_MIN / INT32_MAX (the kernel's own
+    "no row" filler is INT32_MIN), negative and maximal alignment lengths, accession ranks up to 2^32 - 1, perc_identity
+    of -inf / -0.0 / subnormal / 1e308 / +inf (f64 layout) and milli-percent values up to 2^32 - 1 (packed layout):
+    every width of the stream kernel, its long pass and the worklist kernel against the oracle."""
+    tax = synth.make_taxonomy(3000, 91)
+    t = _engine_tax(tax, "custom", H.CUSTOM_16S)
+    dh = synth.make_hits(tax, 600, 900 + hits, hits, p_unmatched=0.002)
+    h = dh.numpy()
+    rng = np.random.default_rng(hits)
+    n = len(h["bitscore"])
+    i32 = np.iinfo(np.int32)
+    h["bitscore"] = rng.choice(np.array([i32.min, i32.min + 1, -1, 0, 1, i32.max - 1, i32.max], dtype=np.int32), n)
+    h["align_len"] = rng.choice(np.array([i32.min, -7, 0, 400, i32.max], dtype=np.int32), n)
+    h["acc_rank"] = rng.choice(np.array([0, 1, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF], dtype=np.uint32), n).view(np.int32)
+    rows = t.engine_rows(h["tax_row"])
+    # f64 layout
+    h["pident"] = rng.choice(np.array([-np.inf, -1.0, -0.0, 0.0, 5e-324, 66.667, 97.0, 100.0, 1e308, np.inf]), n)
+    for strategy in ("relaxed", "cautious"):
+        _assert_records_equal(_run_host(t, h, strategy), H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S))
+    # packed layout: any u32 is a milli-percent value; the oracle reads the double k / 1000
+    milli = rng.choice(np.array([0, 1, 66667, 96999, 97000, 100000, 100001, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF], dtype=np.uint32), n)
+    h["pident"] = milli.astype(np.float64) / 1000.0
+    for strategy in ("relaxed", "cautious"):
+        exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S)
+        got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy,
+                                        pident_milli=milli, packed=True)
+        _assert_records_equal(got, exp)
+        got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy,
+                                        pident_milli=milli)
+        _assert_records_equal(got, exp)
