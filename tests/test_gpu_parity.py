@@ -540,3 +540,41 @@ def test_extreme_column_values(hits):
         got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy,
                                         pident_milli=milli)
         _assert_records_equal(got, exp)
+
+
+def test_more_distinct_cutoffs_than_the_lds_table_holds():
+    """Interpolated cutoffs (linnaean_ranks.rs:289-366) depend on how many non-default levels sit between two backbone
+    ranks; 1..60 stacked clades between domain and species give > 512 distinct values, more than the stream kernel
+    keeps in LDS, so the cutoff tests read the global table instead.  Same records as the oracle."""
+    from types import SimpleNamespace
+    names = ["d", "clade", "s"]
+    lin_node, lin_rank, lin_off = [], [], [0]
+    for n in range(1, 61):
+        for sp in range(3):
+            lin_node += [1] + [100 + j for j in range(n)] + [5000 + 3 * n + sp]
+            lin_rank += [0] + [1] * n + [2]
+            lin_off.append(len(lin_node))
+    n_tax = len(lin_off) - 1
+    tax = SimpleNamespace(rank_names=names, lin_off=np.array(lin_off, dtype=np.uint64), lin_node=np.array(lin_node, dtype=np.uint32),
+                          lin_rank=np.array(lin_rank, dtype=np.uint16), taxid=np.arange(1, n_tax + 1, dtype=np.int64), n=n_tax)
+    custom = {"domain": 50, "species": 99}
+    t = _engine_tax(tax, "custom", custom)
+    distinct = set()
+    for row in range(0, n_tax, 3):
+        distinct.update(np.asarray(t.row_cutoffs(row)[0]).view(np.uint64).tolist())
+    assert len(distinct) > 512
+    rng = np.random.default_rng(12)
+    Q = 3000
+    lens = rng.integers(1, 41, Q)
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nrow = int(seg[-1])
+    centre = np.repeat(rng.integers(0, n_tax, Q), lens)
+    rows = np.clip(centre + rng.integers(-4, 5, nrow), 0, n_tax - 1).astype(np.int32)
+    top = np.repeat(rng.integers(100, 900, Q), lens)
+    h = {"seg_off": seg, "bitscore": (top - rng.integers(0, 2, nrow) * rng.integers(1, 50, nrow)).astype(np.int32), "tax_row": rows,
+         "pident": np.round(rng.uniform(50.0, 100.0, nrow), 3), "align_len": rng.integers(380, 480, nrow).astype(np.int32),
+         "acc_rank": rng.integers(0, 1000, nrow).astype(np.int32)}
+    for strategy in ("relaxed", "cautious"):
+        exp = H.columnar(tax, h, "custom", strategy, custom)
+        _assert_records_equal(_run_host(t, h, strategy), exp)
+        assert (exp["status"] <= 1).sum() > Q // 2
