@@ -578,3 +578,24 @@ def test_more_distinct_cutoffs_than_the_lds_table_holds():
         exp = H.columnar(tax, h, "custom", strategy, custom)
         _assert_records_equal(_run_host(t, h, strategy), exp)
         assert (exp["status"] <= 1).sum() > Q // 2
+
+
+@pytest.mark.parametrize("hits", [10, 50, 300, 700, 1500])
+def test_sparse_nan_perc_identity(hits):
+    """NaN perc_identity on a few rows (f64 layout): a query whose top group holds one gets BLU_ST_ERR_BAD_PIDENT at
+    the group's first NaN row in file order — after the parse errors, which win — and every other query is
+    untouched; stream kernel widths, long pass and worklist kernel against the oracle."""
+    tax = synth.make_taxonomy(3000, 17)
+    bad = (np.arange(tax.n) % 41 == 0).astype(np.uint8)
+    t = _engine_tax(tax, "custom", H.CUSTOM_16S, bad=bad)
+    h = synth.make_hits(tax, 800 if hits <= 300 else 300, 1700 + hits, hits, p_unmatched=0.002).numpy()
+    rng = np.random.default_rng(hits)
+    bs = h["bitscore"].reshape(-1, hits).copy()
+    bs[:, : max(2, hits // 8)] = bs.max(axis=1, keepdims=True)          # top groups wide enough to catch a NaN
+    h["bitscore"] = bs.reshape(-1)
+    h["pident"][rng.random(len(h["pident"])) < 0.02] = np.nan
+    for strategy in ("relaxed", "cautious"):
+        exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S, bad=bad)
+        _assert_records_equal(_run_host(t, h, strategy), exp)
+        st = set(exp["status"].tolist())
+        assert N.ST_ERR_BAD_PIDENT in st and (0 in st or hits >= 300)
