@@ -1024,6 +1024,7 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
         uint32_t k = 0, err_status = 0, err_row = 0;
         uint32_t have = 0, b_len = 0, b_acc = 0, b_pos = 0, b_row = 0, l_minlen = 0xFFFFFFFFu;
         uint32_t l_lo = 0xFFFFFFFFu, l_hi = 0;   // span of this lane's top rows in the sorted lineage order
+        uint32_t l_nan = 0xFFFFFFFFu;             // this lane's first top row with a NaN perc_identity (f64 layout only)
         int b_aln = 0;
         double b_pid = 0.0, l_maxpid = 0.0;
         for (uint64_t sb = 0; sb < n && err_status == 0; sb += LONG_SPAN) {
@@ -1078,6 +1079,7 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
             l_lo = top ? umin(l_lo, pos) : l_lo;
             l_hi = (top && pos > l_hi) ? pos : l_hi;
             l_maxpid = (top && pid > l_maxpid) ? pid : l_maxpid;
+            if (!PID32) l_nan = (top && pid != pid) ? umin(l_nan, i) : l_nan;
             }
           }
           if (it_err_status) { err_status = it_err_status; err_row = it_err_row; }
@@ -1087,17 +1089,10 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
             if (lane == 0) store_status(out, q, err_status, (uint32_t)start + err_row);
             continue;
         }
-        // NaN pident anywhere in the top group: second scan in file order (rare path kept simple; the milli-percent
-        // layout has no NaN)
+        // NaN pident anywhere in the top group (after the parse errors, which win): its first row in file order, gathered
+        // by pass 2 (the milli-percent layouts have no NaN)
         if (!PID32) {
-            uint32_t nan_row = 0xFFFFFFFFu;
-            for (uint64_t base = 0; base < n; base += WAVE) {
-                const uint64_t i = base + (uint32_t)lane;
-                const bool top = i < n && c_bs[i < n ? i : 0] == M;
-                const double pid = c_pid[top ? i : 0];
-                const uint64_t nm = __ballot(top && pid != pid);
-                if (nm) { nan_row = (uint32_t)base + (uint32_t)first_lane(nm); break; }
-            }
+            const uint32_t nan_row = wave_min_u32(l_nan);
             if (nan_row != 0xFFFFFFFFu) {
                 if (lane == 0) store_status(out, q, BLU_ST_ERR_BAD_PIDENT, (uint32_t)start + nan_row);
                 continue;
