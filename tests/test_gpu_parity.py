@@ -599,3 +599,29 @@ def test_sparse_nan_perc_identity(hits):
         _assert_records_equal(_run_host(t, h, strategy), exp)
         st = set(exp["status"].tolist())
         assert N.ST_ERR_BAD_PIDENT in st and (0 in st or hits >= 300)
+
+
+def test_degenerate_tables():
+    """No rows at all (every query empty), a single query, a single row, zero queries: host and device pointers."""
+    import torch
+    tax = synth.make_taxonomy(200, 3)
+    t = _engine_tax(tax, "bacteria")
+    z32, zf = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.float64)
+    # zero queries: nothing to do, nothing touched
+    got = engine.run_consensus_host(t, np.zeros(1, dtype=np.int64), z32, z32, zf, z32, z32, "relaxed")
+    assert len(got) == 0
+    # 1000 queries, no rows
+    seg = np.zeros(1001, dtype=np.int64)
+    got = engine.run_consensus_host(t, seg, z32, z32, zf, z32, z32, "relaxed")
+    assert (got["status"] == N.ST_NO_HITS).all() and (got["ref_row"] == 0xFFFFFFFF).all()
+    out = torch.full((32 * 1000,), 7, dtype=torch.uint8, device="cuda")
+    dev = {"seg_off": torch.zeros(1001, dtype=torch.int64, device="cuda"), "bitscore": torch.zeros(0, dtype=torch.int32, device="cuda"),
+           "packed": torch.zeros(0, dtype=torch.int32, device="cuda")}
+    engine.run_consensus_device(t, dev, out, strategy="cautious")
+    torch.cuda.synchronize()
+    assert engine.records_from_tensor(out).tobytes() == got.tobytes()
+    # one query of one row / of 3000 rows
+    for rows_n in (1, 3000):
+        h = synth.make_hits(tax, 1, 40 + rows_n, rows_n, p_unmatched=0.0).numpy()
+        for strategy in ("relaxed", "cautious"):
+            _assert_records_equal(_run_host(t, h, strategy), H.columnar(tax, h, "bacteria", strategy))
