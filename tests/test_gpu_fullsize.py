@@ -13,6 +13,16 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _give_device_memory_back():
+    """These tests hold up to ~110 GB in torch's caching allocator; the library allocates with hipMalloc directly."""
+    yield
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def test_c3_full_size_properties():
     import torch
     cfg = synth.CONFIGS["C3"]
