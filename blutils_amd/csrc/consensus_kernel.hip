@@ -238,6 +238,9 @@ static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 #ifndef SHORT_SEG
 #define SHORT_SEG 128u           // segments up to here are streamed (4 .. 32 lanes per query); longer ones take the sparse long pass
 #endif
+#ifndef BLU_LONG_COST
+#define BLU_LONG_COST 96u   // lane-steps one query costs in the long pass (half a 64-lane step, not pipelined; 64 / 96 / 128 / 192 measured)
+#endif
 #define MAX_TASK_SEG 512u        // longest segment the stream kernel takes (64 lanes x 4 rows, twice); longer ones go to the worklist
 #ifndef BLOCK_B
 #define BLOCK_B 256
@@ -403,6 +406,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             L.list[idx] = e;
         };
         uint32_t stop_q = WAVE;      // first query index phase 1 did not get to in this round (the list was full), or 64
+        uint32_t short_seg = SHORT_SEG;   // longest segment the streamed pass takes in this round (longer ones: the long pass)
         uint32_t first_q = 0;        // first pending query of the round
         auto phase1 = [&](const auto lpq, const bool sparse8) {   // wave-uniform width: a constant for 16 lanes, a variable otherwise
         const uint32_t LPQ = lpq;
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             R.qi = qb + grp;                                     // this lane's query (>= nq: empty slot of the table)
             const uint2 sg = L.seg[R.qi];
             // rows of the segment from this lane's first row on (segments over SHORT_SEG rows belong to the long pass)
-            R.left = (sg.y > SHORT_SEG ? 0 : (int)sg.y) - (int)sub4;
+            R.left = (sg.y > short_seg ? 0 : (int)sg.y) - (int)sub4;
             const uint32_t voff = R.left > 0 ? (sg.x + sub4) * 4u : 0xFFFFFFF0u;
             R.vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
             if (sparse) return;                                  // the other columns: for top rows only, in tops()
@@ -663,12 +667,31 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             const uint32_t rows = L.seg[lane].y;                    // this lane's query (0: empty, done, too long, or outside the span)
             const uint64_t live = __ballot(rows != 0u);
             first_q = live ? (uint32_t)__builtin_ctzll(live) : 0u;
-            const uint32_t longest = wave_max_u32(rows > SHORT_SEG ? 0u : rows);   // longest streamed segment of the task
+#ifndef BLU_FIXED_WIDTH
+            // Width of the streamed pass.  Every streamed query pays the lanes of the widest one, so a few long segments
+            // among short ones (Zipf-like hit counts) are cheaper in the long pass: estimated cost in lane-steps =
+            // streamed queries x lanes per query + BLU_LONG_COST per query left to the long pass; smallest wins, ties to
+            // the wider pass.
+            {
+                const uint32_t n16 = (uint32_t)__builtin_popcountll(__ballot(rows != 0u && rows <= 16u));
+                const uint32_t n32 = (uint32_t)__builtin_popcountll(__ballot(rows != 0u && rows <= 32u));
+                const uint32_t n64 = (uint32_t)__builtin_popcountll(__ballot(rows != 0u && rows <= 64u));
+                const uint32_t n128 = (uint32_t)__builtin_popcountll(__ballot(rows != 0u && rows <= SHORT_SEG));
+                const uint32_t c16 = 4u * n16 + BLU_LONG_COST * (n128 - n16), c32 = 8u * n32 + BLU_LONG_COST * (n128 - n32);
+                const uint32_t c64 = 16u * n64 + BLU_LONG_COST * (n128 - n64), c128 = 32u * n128;
+                uint32_t best = c128;
+                short_seg = SHORT_SEG;
+                if (c64 < best) { best = c64; short_seg = 64u; }
+                if (c32 < best) { best = c32; short_seg = 32u; }
+                if (c16 < best) { best = c16; short_seg = 16u; }
+            }
+#endif
+            const uint32_t longest = wave_max_u32(rows > short_seg ? 0u : rows);   // longest streamed segment of the task
             if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>(), false);   // the C3 shape, specialised
             else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u), longest >= (PACKED ? 9u : 25u));   // two-stage steps: measured break-even (packed records: 10 hits -2.5 %, 20 hits -17 %; columns: 20 hits +3 %, 30 hits -6 %)
             // queries phase 1 did not get to (the list filled up): marked for the next round, long ones included
-            if (stop_q < WAVE && rows != 0u && ((uint32_t)lane >= stop_q || rows > SHORT_SEG)) L.meta[lane] = META_SLOW;
-            const uint64_t long_mask = __ballot(rows > SHORT_SEG);
+            if (stop_q < WAVE && rows != 0u && ((uint32_t)lane >= stop_q || rows > short_seg)) L.meta[lane] = META_SLOW;
+            const uint64_t long_mask = __ballot(rows > short_seg);
             if (long_mask && stop_q == WAVE) phase1_long(long_mask);   // after the streamed pass: it overwrites their (empty) list heads
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
