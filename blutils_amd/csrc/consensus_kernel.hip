@@ -1025,11 +1025,11 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
         // 16-byte loads, four per lane in flight (1024 rows per iteration); rows past the segment read as 0 from the
         // range-checked descriptor and are masked by index
         int m = INT_MIN;
+        u32x4 v[4] = {};   // (a segment of up to 1024 rows stays in these registers for pass 2)
         for (uint64_t sb = 0; sb < n; sb += LONG_SPAN) {   // descriptors cover LONG_SPAN rows: byte offsets stay below 2^32
             const uint32_t ns = (n - sb) < LONG_SPAN ? (uint32_t)(n - sb) : LONG_SPAN;
             const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(c_bs + sb), 0, ns * 4u, 0x00020000);
             for (uint32_t base = 0; base < ns; base += 1024) {
-                u32x4 v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
 #pragma unroll
@@ -1057,9 +1057,10 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
           // 1024 rows per round trip, as in pass 1 (four 16-byte loads per lane in flight); top rows are sparse, so most of
           // the sixteen 64-row groups end at the ballot.  Lane l holds rows base + 256 u + 4 l + c: a lane sees its rows
           // in file order, which is all the running selects below need (ties across lanes are settled by row index).
-          u32x4 v[4];
+          if (n > 1024u) {   // (wave-uniform) a shorter segment is still in the registers pass 1 filled: one round trip less
 #pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
+              for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
+          }
           uint32_t it_err_row = 0xFFFFFFFFu, it_err_status = 0;   // first failing row of this round trip, in file order
           for (int u = 0; u < 4; ++u) {
             if (base + (uint32_t)u * 256 >= ns) break;

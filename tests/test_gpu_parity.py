@@ -625,3 +625,46 @@ def test_degenerate_tables():
         h = synth.make_hits(tax, 1, 40 + rows_n, rows_n, p_unmatched=0.0).numpy()
         for strategy in ("relaxed", "cautious"):
             _assert_records_equal(_run_host(t, h, strategy), H.columnar(tax, h, "bacteria", strategy))
+
+
+@pytest.mark.parametrize("order", ["ascending", "descending", "shuffled", "peak_in_the_middle"])
+def test_worklist_kernel_score_orders(order):
+    """Long segments (1100..5000 rows: several 1024-row round trips of the worklist kernel, plus some under 1024 rows that
+    stay in registers between its two passes) whose scores rise along the file, fall (BLAST's own order), are shuffled,
+    or peak in the middle, with plateaus of equal scores; unmatched taxids, unparseable lineages and NaN identities
+    sit in rows that are NOT in the top group and must not matter.  f64 and packed layouts against the oracle."""
+    tax = synth.make_taxonomy(3000, 23)
+    bad = (np.arange(tax.n) % 29 == 0).astype(np.uint8)
+    t = _engine_tax(tax, "custom", H.CUSTOM_16S, bad=bad)
+    rng = np.random.default_rng(len(order))
+    lens = np.concatenate([rng.integers(1100, 5001, 100), rng.integers(513, 1025, 20)])
+    rng.shuffle(lens)
+    base = synth.make_hits(tax, len(lens), 77, 5000, p_unmatched=0.01).numpy()
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    take = np.concatenate([np.arange(l) + 5000 * i for i, l in enumerate(lens)])
+    h = {k: (base[k][take] if k != "seg_off" else seg) for k in base}
+    bs = np.empty(int(seg[-1]), dtype=np.int32)
+    for i, l in enumerate(lens):
+        steps = np.sort(rng.integers(0, 60, l)) * 7 + 100            # plateaus: several rows share every score
+        if order == "descending":
+            steps = steps[::-1]
+        elif order == "shuffled":
+            rng.shuffle(steps)
+        elif order == "peak_in_the_middle":
+            steps = np.concatenate([steps[::2], steps[1::2][::-1]])
+        bs[seg[i]:seg[i + 1]] = steps
+    h["bitscore"] = bs
+    h["pident"][rng.random(len(bs)) < 0.01] = np.nan
+    rows = t.engine_rows(h["tax_row"])
+    for strategy in ("relaxed", "cautious"):
+        exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S, bad=bad, threads=8)
+        _assert_records_equal(_run_host(t, h, strategy), exp)
+    assert len(set(exp["status"].tolist())) >= 3
+    # packed layout (no NaN there: milli-percent values)
+    milli = np.where(np.isnan(h["pident"]), 0, np.round(np.nan_to_num(h["pident"]) * 1000)).astype(np.uint32)
+    h["pident"] = milli.astype(np.float64) / 1000.0
+    for strategy in ("relaxed", "cautious"):
+        exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S, bad=bad, threads=8)
+        got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy,
+                                        pident_milli=milli, packed=True)
+        _assert_records_equal(got, exp)
