@@ -171,3 +171,33 @@ def test_shard_ranges_match_the_python_sharding():
             exp = shard.balanced_query_ranges(seg, parts)
             assert [(int(got[i]), int(got[i + 1])) for i in range(parts)] == exp
             assert got[0] == 0 and got[-1] == nq and np.all(np.diff(got.astype(np.int64)) >= 0)
+
+
+def test_sharded_run_validates_the_offset_table_before_touching_a_device():
+    """blu_consensus_run_multi cuts the host table by its offsets: a non-ascending table, or one that runs past n_hits,
+    is refused as data (BLU_ERR_INVALID_ARG) — with host-only handles, i.e. before any device is asked for."""
+    import ctypes as C
+    tax = synth.make_taxonomy(100, 1)
+    a, b = _host_tax(tax, "bacteria"), _host_tax(tax, "bacteria")
+    h = synth.make_hits(tax, 10, 2, 5).numpy()
+    L = N.lib()
+    L.blu_consensus_run_multi.restype = C.c_int
+    L.blu_consensus_run_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    out = np.zeros(10, dtype=engine.RESULT_DTYPE)
+    params = N.RunParams(N.STRATEGY["relaxed"], 0, None)
+    handles = (C.c_void_p * 2)(a.handle, b.handle)
+    cols = [np.ascontiguousarray(h[k]) for k in ("bitscore", "tax_row", "pident", "align_len", "acc_rank")]
+
+    def run(seg, nh, hs=handles, n=2):
+        seg = np.ascontiguousarray(seg, dtype=np.uint64)
+        hits = N.Hits(cols[0].ctypes.data, cols[1].ctypes.data, cols[2].ctypes.data, cols[3].ctypes.data, cols[4].ctypes.data,
+                      seg.ctypes.data, nh, len(seg) - 1, 0, 0, None, None)
+        return L.blu_consensus_run_multi(hs, n, C.byref(hits), C.byref(params), out.ctypes.data)
+
+    seg = h["seg_off"].astype(np.uint64)
+    assert run(seg, 40) == N.BLU_ERR_INVALID_ARG                      # offsets run to 50, the table holds 40 rows
+    bad = seg.copy()
+    bad[3], bad[4] = bad[4], bad[3]
+    assert run(bad, 50) == N.BLU_ERR_INVALID_ARG                      # not ascending
+    assert run(seg, 50, (C.c_void_p * 2)(a.handle, a.handle)) == N.BLU_ERR_INVALID_ARG   # one handle twice
+    assert run(seg, 50) == N.BLU_ERR_NO_DEVICE                        # well-formed: only now a device is needed
