@@ -95,7 +95,7 @@ typedef struct blu_hits {
     const int32_t* align_len;  /* [n_hits] */
     const uint32_t* acc_rank;  /* [n_hits] order-preserving rank of subject_accession (bytewise String::cmp) */
     const uint64_t* seg_off;   /* [n_queries + 1] row offsets, seg_off[0] = 0, seg_off[n_queries] = n_hits */
-    uint64_t n_hits;           /* < 2^32 per call */
+    uint64_t n_hits;           /* < 2^32 - 1 per call (0xFFFFFFFF is the "no row" value of blu_result.ref_row) */
     uint64_t n_queries;
     int32_t on_device;         /* 1: every pointer (and `out`) is a device pointer on the handle's GPU;
                                   0: host pointers, the library stages them over PCIe */
