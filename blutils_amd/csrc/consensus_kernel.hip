@@ -1025,6 +1025,7 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
         // 16-byte loads, four per lane in flight (1024 rows per iteration); rows past the segment read as 0 from the
         // range-checked descriptor and are masked by index
         int m = INT_MIN;
+        uint32_t c_first = 0, c_last = 0;   // first / last 1024-row chunk (its first row) in which this lane saw its running maximum
         u32x4 v[4] = {};   // (a segment of up to 1024 rows stays in these registers for pass 2)
         for (uint64_t sb = 0; sb < n; sb += LONG_SPAN) {   // descriptors cover LONG_SPAN rows: byte offsets stay below 2^32
             const uint32_t ns = (n - sb) < LONG_SPAN ? (uint32_t)(n - sb) : LONG_SPAN;
@@ -1032,17 +1033,26 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
             for (uint32_t base = 0; base < ns; base += 1024) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
+                int cl = INT_MIN;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t i0 = base + u * 256 + (uint32_t)lane * 4u;
-                    m = imax(m, i0 < ns ? (int)v[u].x : INT_MIN);
-                    m = imax(m, i0 + 1 < ns ? (int)v[u].y : INT_MIN);
-                    m = imax(m, i0 + 2 < ns ? (int)v[u].z : INT_MIN);
-                    m = imax(m, i0 + 3 < ns ? (int)v[u].w : INT_MIN);
+                    cl = imax(cl, i0 < ns ? (int)v[u].x : INT_MIN);
+                    cl = imax(cl, i0 + 1 < ns ? (int)v[u].y : INT_MIN);
+                    cl = imax(cl, i0 + 2 < ns ? (int)v[u].z : INT_MIN);
+                    cl = imax(cl, i0 + 3 < ns ? (int)v[u].w : INT_MIN);
                 }
+                const uint32_t cb = (uint32_t)sb + base;
+                c_first = cl > m ? cb : c_first;
+                c_last = cl >= m ? cb : c_last;
+                m = imax(m, cl);
             }
         }
         const int M = wave_max_i32(m);
+        // pass 2 only walks the chunks that can hold a top row: BLAST writes a query's hits best first, so this is
+        // usually the first chunk alone (lanes that never reached M do not count; chunk starts are multiples of 1024)
+        const uint32_t w_first = wave_min_u32(m == M ? c_first : 0xFFFFFFFFu);
+        const uint32_t w_last = wave_max_u32(m == M ? c_last : 0u);
         // pass 2: group size, errors in file order, lane-local best key / shortest lineage / max pident
         uint32_t k = 0, err_status = 0, err_row = 0;
         uint32_t have = 0, b_len = 0, b_acc = 0, b_pos = 0, b_row = 0, l_minlen = 0xFFFFFFFFu;
@@ -1050,10 +1060,12 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
         uint32_t l_nan = 0xFFFFFFFFu;             // this lane's first top row with a NaN perc_identity (f64 layout only)
         int b_aln = 0;
         double b_pid = 0.0, l_maxpid = 0.0;
-        for (uint64_t sb = 0; sb < n && err_status == 0; sb += LONG_SPAN) {
+        for (uint64_t cb = w_first; cb <= w_last && cb < n && err_status == 0; cb += 1024) {
+        {
+        const uint64_t sb = cb / LONG_SPAN * LONG_SPAN;
+        const uint32_t base = (uint32_t)(cb - sb);
         const uint32_t ns = (n - sb) < LONG_SPAN ? (uint32_t)(n - sb) : LONG_SPAN;
         const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(c_bs + sb), 0, ns * 4u, 0x00020000);
-        for (uint32_t base = 0; base < ns && err_status == 0; base += 1024) {
           // 1024 rows per round trip, as in pass 1 (four 16-byte loads per lane in flight); top rows are sparse, so most of
           // the sixteen 64-row groups end at the ballot.  Lane l holds rows base + 256 u + 4 l + c: a lane sees its rows
           // in file order, which is all the running selects below need (ties across lanes are settled by row index).
