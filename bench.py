@@ -5,13 +5,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (blu_consensus_run -> one HIP kernel launch) over the whole
-synthetic hit table of this rank, inputs already resident in HBM.  Workload at N=1: BASELINE config #3
-(10M queries x 50 hits, 2.4M-taxid synthetic taxonomy, relaxed strategy, custom 16S cutoffs).  For N>1
-every rank holds its own 10M-query slice (weak scaling: queries are independent, taxonomy replicated,
-no data-path collective).  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path (blu_consensus_run -> the HIP kernels) over the whole synthetic hit table of this
+rank, inputs already resident in HBM.
+
+* N = 1: BASELINE config 3 (10 M queries x 50 hits, 2.4 M-taxid synthetic taxonomy, relaxed strategy, custom 16S cutoffs).
+* N > 1: BASELINE config 4 — the SAME 10 M-query table cut into N contiguous query ranges balanced by hit count
+  (blutils_amd/shard.py), one range per rank, taxonomy replicated, no data-path collective ("scaling": "strong").  The
+  weak-scaling figure (every rank a 10 M-query table of its own) is measured in the same run and reported as the
+  secondary field `weak_scaling`.  `--scaling weak` makes it the headline instead.
+
+Rank 0 prints ONE JSON line.  `roofline`:
+  useful_bytes   bytes the reference semantics need from this table: every bit-score (4 H), the other 16 B (20 B in the
+                 f64 layout) of the T top-score rows only, the offsets 8 (Q + 1) and the records 32 Q; T is counted on
+                 the device from the timed table.  `achieved` / `frac` are priced with these.
+  by_formula     SURVEY 8d's per-unit figure, 20 (or 24) B per hit row: an upper bound on what a kernel may read.
+  traffic        HBM bytes per launch from the PMC passes of profiles/ (profiles/hbm_traffic.json), quoted only when
+                 that file was taken with the kernel source of this tree (sha256 match) and this workload; else null.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,6 +37,7 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MIC
 CPU_THREADS_CAP = 16     # worker threads for the CPU legs (the box's CPU share for one GPU)
 CUSTOM_16S = {"domain": 50, "kingdom": 60, "phylum": 75, "class": 80, "order": 85, "family": 92, "genus": 97,
               "species": 99}   # reference assets/custom-taxon-cutoffs-bacteria-16S.yaml
+KERNEL_SOURCES = ("blutils_amd/csrc/consensus_kernel.hip", "blutils_amd/csrc/blu_internal.h")
 
 
 LAYOUT_TEXT = {"packed": "bit-score column + 16-byte side records, perc_identity as milli-percent u32 (lossless, 20 B/hit)",
@@ -36,21 +49,55 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def kernel_source_sha256() -> str:
+    """Identity of the kernel the counters in profiles/hbm_traffic.json belong to."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def count_top_rows(hits) -> int:
+    """T = rows that tie on their query's top bit-score (all the reference ever parses beyond the score column:
+    find_single_query_consensus.rs:51-64), counted on the device."""
+    import torch
+    seg = hits.seg_off
+    Q = hits.n_queries
+    total = 0
+    step = 1 << 20
+    for q0 in range(0, Q, step):
+        q1 = min(Q, q0 + step)
+        r0, r1 = int(seg[q0].item()), int(seg[q1].item())
+        if r1 == r0:
+            continue
+        lens = seg[q0 + 1:q1 + 1] - seg[q0:q1]
+        qid = torch.repeat_interleave(torch.arange(q1 - q0, device=seg.device), lens)
+        bs = hits.bitscore[r0:r1]
+        top = torch.full((q1 - q0,), -(1 << 31), dtype=torch.int32, device=seg.device)
+        top.scatter_reduce_(0, qid, bs, reduce="amax", include_self=True)
+        total += int((bs == top[qid]).sum().item())
+    return total
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C5"])
-    ap.add_argument("--queries", type=int, default=0, help="override the number of queries per GPU")
+    ap.add_argument("--queries", type=int, default=0, help="override the number of queries of the table")
     ap.add_argument("--taxa", type=int, default=0, help="override the number of taxids")
     ap.add_argument("--hits-per-query", type=int, default=0, help="override the hits per query of C2 / C3 (blutils' own default is max_target_seqs = 10)")
+    ap.add_argument("--top-group", default="geo", choices=["geo", "zymo", "all"],
+                    help="size of the top bit-score group: geo = 1 + Geometric(0.35) (SURVEY 8d, the headline); zymo = histogram of "
+                         "the reference's real zymo-mock output (mean 5.7); all = every hit ties (table read in full)")
     ap.add_argument("--strategy", default="relaxed", choices=["relaxed", "cautious"])
     ap.add_argument("--taxon", default="custom", choices=["custom", "bacteria", "fungi", "eukaryotes"])
     ap.add_argument("--cpu-sample", type=int, default=500000, help="queries of the workload timed on the CPU oracle")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank holds the full per-GPU workload; strong: the workload is split over the ranks "
-                         "(BASELINE config #4: 10M queries sharded across 8 GPUs)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="auto: strong for N > 1 (BASELINE config 4: ONE table sharded over the ranks), with the weak figure as a "
+                         "secondary field; weak: every rank holds a full table of its own")
     ap.add_argument("--pident", default="packed", choices=["packed", "milli", "f64"],
                     help="hit-table layout: packed = bit-score column + 16-byte side records {tax_row, pident_milli, "
                          "align_len, acc_rank} (20 B/hit; a top row's values sit in one memory line); milli = five "
@@ -60,25 +107,33 @@ def main():
                     help="capture one run (both kernels) in a HIP graph and time replays: for launch-bound sizes (C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary weak-scaling measurement of an N > 1 run")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    from blutils_amd import engine, synth
+    from blutils_amd import engine, shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1 or os.environ.get("BLU_BENCH_FORCE_DIST") == "1"   # (the override lets a 1-GPU box rehearse the RCCL path)
+    force_dist = os.environ.get("BLU_BENCH_FORCE_DIST") == "1"   # lets a 1-GPU box rehearse the RCCL path and the N > 1 defaults
+    distributed = world > 1 or force_dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    backend = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+        backend = f"{dist.get_backend()} (RCCL), world_size {dist.get_world_size()}"
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if distributed else "weak")
 
     cfg = dict(synth.CONFIGS[args.config])
     if args.queries:
@@ -87,10 +142,9 @@ def main():
         cfg["n_taxa"] = args.taxa
     if args.hits_per_query and cfg["zipf"] is None:
         cfg["hits_per_query"] = args.hits_per_query
-    if args.scaling == "strong" and world > 1:
-        cfg["n_queries"] = (cfg["n_queries"] + world - 1) // world      # per-GPU query slice of one fixed table
     seed = synth.SEEDS[args.config]
     custom = CUSTOM_16S if args.taxon == "custom" else None
+    Q_table = cfg["n_queries"]                       # queries of ONE table (strong: cut over the ranks; weak: per rank)
 
     t0 = time.time()
     tax = synth.make_taxonomy(cfg["n_taxa"], seed, deep=cfg["deep"])
@@ -99,32 +153,50 @@ def main():
     eng_tax = engine.Taxonomy(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, taxon=args.taxon,
                               custom=custom, device=local_rank)
     t_up = time.time() - t0
-    t0 = time.time()
-    hits = synth.make_hits(tax, cfg["n_queries"], seed, cfg["hits_per_query"], zipf=cfg["zipf"], device=dev,
-                           q_offset=rank * cfg["n_queries"], columns="f64" if args.pident == "f64" else "milli")
-    torch.cuda.synchronize()
-    t_hits = time.time() - t0
+
+    def query_range(mode):
+        """[q0, q1) of this rank in the global query numbering."""
+        if mode == "weak" or world == 1:
+            return rank * Q_table, (rank + 1) * Q_table
+        if cfg["zipf"] is None:                      # hit-balanced contiguous ranges of the one table (shard.py)
+            seg = np.arange(Q_table + 1, dtype=np.int64) * cfg["hits_per_query"]
+        else:                                        # the skewed table: its hit counts come from the generator
+            seg = np.concatenate([[0], np.cumsum(synth.hit_counts(Q_table, seed, None, cfg["zipf"], dev).cpu().numpy())])
+        return shard.balanced_query_ranges(seg, world)[rank]
+
+    def build_table(mode):
+        q0, q1 = query_range(mode)
+        t0 = time.time()
+        hits = synth.make_hits(tax, q1 - q0, seed, cfg["hits_per_query"], zipf=cfg["zipf"], device=dev, q_offset=q0,
+                               columns="f64" if args.pident == "f64" else "milli", top_group=args.top_group)
+        torch.cuda.synchronize()
+        t_hits = time.time() - t0
+        hd = hits.as_dict("f64" if args.pident == "f64" else "milli")
+        # the join of the hit table with the taxonomy (mod.rs:72-76): desc row -> engine row id, done once at ingest.
+        # The oracle legs read the desc rows of the sampled prefix, kept aside.
+        S_keep = min(hits.n_queries, max(args.cpu_sample, 1))
+        desc_rows_sample = hd["tax_row"][: int(hits.seg_off[S_keep].item())].cpu().numpy()
+        for a in range(0, hits.n_hits, 1 << 26):
+            b = min(hits.n_hits, a + (1 << 26))
+            hd["tax_row"][a:b] = eng_tax.engine_rows(hd["tax_row"][a:b])
+        cols = hd            # the five columns (kept for the oracle sample below)
+        if args.pident == "packed":
+            hits.tax_row = hd["tax_row"]
+            hd = hits.as_dict("packed")
+        out = torch.zeros(32 * hits.n_queries, dtype=torch.uint8, device=dev)
+        return hits, hd, cols, desc_rows_sample, out, t_hits
+
+    hits, hd, cols, desc_rows_sample, out, t_hits = build_table(scaling)
     Q, Hn = hits.n_queries, hits.n_hits
-    out = torch.zeros(32 * Q, dtype=torch.uint8, device=dev)
-    hd = hits.as_dict("f64" if args.pident == "f64" else "milli")
-    # the join of the hit table with the taxonomy (mod.rs:72-76): desc row -> engine row id, done once at ingest.
-    # The oracle legs read the desc rows of the sampled prefix, kept aside.
-    S_keep = min(Q, max(args.cpu_sample, 1))
-    desc_rows_sample = hd["tax_row"][: int(hits.seg_off[S_keep].item())].cpu().numpy()
-    for a in range(0, Hn, 1 << 26):
-        b = min(Hn, a + (1 << 26))
-        hd["tax_row"][a:b] = eng_tax.engine_rows(hd["tax_row"][a:b])
-    cols = hd            # the five columns (kept for the oracle sample below)
-    if args.pident == "packed":
-        hits.tax_row = hd["tax_row"]
-        hd = hits.as_dict("packed")
     if rank == 0:
         log(f"[bench] taxonomy {tax.n} taxids ({t_tax:.1f}s gen, {t_up:.1f}s upload, {eng_tax.n_shapes} shapes, "
             f"depth<={eng_tax.max_depth}, {eng_tax.device_bytes / 1e6:.0f} MB on device); "
-            f"hits {Q} queries / {Hn} rows ({t_hits:.1f}s gen on GPU)")
+            f"hits {Q} queries / {Hn} rows on this rank ({t_hits:.1f}s gen on GPU); scaling {scaling}, world {world}")
+
+    state = {"hd": hd, "out": out}
 
     def step():
-        engine.run_consensus_device(eng_tax, hd, out, strategy=args.strategy)
+        engine.run_consensus_device(eng_tax, state["hd"], state["out"], strategy=args.strategy)
 
     # ---- parity gate (rank 0): GPU records of a sample == columnar oracle, before any timing is accepted
     cpu_baseline = None
@@ -161,6 +233,7 @@ def main():
                                       f"queries, {dt:.2f} s wall"}
             log(f"[bench] cpu baseline: {cpu_baseline['value']:.4f} Mq/s on {cores} threads ({dt:.2f}s)")
 
+    run_step = step
     if args.graph:
         # the run leaves its worklist counters as it found them, so the captured pair of kernels can be replayed
         side = torch.cuda.Stream()
@@ -170,71 +243,119 @@ def main():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
             step()
-        step = graph.replay
+        run_step = graph.replay
 
-    # ---- timed region
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    def timed(fn):
+        """W untimed + K timed steps between barriers; (wall seconds, max over ranks; this rank's per-step event times)."""
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t_start = time.perf_counter()
+        for a, b in ev:
+            a.record()          # torch's current stream == the stream the kernels are launched on
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t_start
+        kernel_ms = [a.elapsed_time(b) for a, b in ev]
+        if distributed:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, kernel_ms
+
+    # ---- timed region (the headline)
+    elapsed, kernel_ms = timed(run_step)
+    total_q = Q
     if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t_start = time.perf_counter()
-    for a, b in ev:
-        a.record()          # torch's current stream == the stream the kernel is launched on
-        step()
-        b.record()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tq = torch.tensor([Q], dtype=torch.int64, device=dev)
+        dist.all_reduce(tq)
+        total_q = int(tq.item())
+    T_top = count_top_rows(hits)
+    name, grid, block = engine.last_launch()
+
+    # ---- secondary: the other scaling mode of an N > 1 run, same process, same K / W
+    secondary = None
+    if distributed and not args.no_secondary and not args.graph and args.scaling == "auto":
+        del hd, cols, out
+        state["hd"] = state["out"] = None
+        hits = None
+        torch.cuda.empty_cache()
+        hits2, hd2, _, _, out2, _ = build_table("weak")
+        state["hd"], state["out"] = hd2, out2
+        e2, _ = timed(step)
+        tq = torch.tensor([hits2.n_queries], dtype=torch.int64, device=dev)
+        dist.all_reduce(tq)
+        secondary = {"scaling": "weak", "value": int(tq.item()) * args.steps / e2 / 1e6, "unit": "Mqueries/s",
+                     "ms_per_step": e2 * 1e3 / args.steps, "queries_per_gpu": hits2.n_queries,
+                     "note": "every rank holds a full table of its own (per-GPU work fixed as N grows)"}
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
-        total_q = Q * world
         value = total_q * args.steps / elapsed / 1e6
         k_ms = float(np.mean(kernel_ms))
-        alg_bytes = hits.algorithmic_bytes(args.pident)
-        traffic = None
+        row_bytes = 24 if args.pident == "f64" else 20
+        alg_bytes = row_bytes * Hn + 8 * (Q + 1) + 32 * Q
+        useful = 4 * Hn + (row_bytes - 4) * T_top + 8 * (Q + 1) + 32 * Q
+        gbps = lambda b: b / (k_ms * 1e-3) / 1e9
+        traffic, traffic_note = None, None
+        default_workload = not (args.queries or args.taxa or args.hits_per_query) and args.top_group == "geo" and world == 1
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile) and not (args.queries or args.taxa or args.hits_per_query):
+        tkey = args.config + "-" + args.pident
+        if not default_workload:
+            traffic_note = "no PMC passes for this workload"
+        elif not os.path.exists(tfile):
+            traffic_note = "profiles/hbm_traffic.json missing"
+        else:
             try:
-                tkey = args.config if args.pident == "f64" else args.config + "-" + args.pident
-                traffic = json.load(open(tfile)).get(tkey, {}).get("traffic_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # the per-unit byte formula, but "never a larger figure than what is physically read" — the stream
-        # kernel skips the lines of the four non-bit-score columns that hold no top row, so on C3 the PMC-measured
-        # traffic of a launch (same seeded table) is BELOW the formula; the smaller of the two prices the roofline
-        used_bytes = min(alg_bytes, traffic) if traffic else alg_bytes
-        achieved = used_bytes / (k_ms * 1e-3) / 1e9
-        name, grid, block = engine.last_launch()
+                ent = json.load(open(tfile)).get(tkey)
+                if ent is None:
+                    traffic_note = f"no PMC passes for {tkey}"
+                elif ent.get("kernel_sha256") != kernel_source_sha256():
+                    traffic_note = f"PMC passes of {tkey} were taken with another kernel source (sha256 mismatch): not quoted"
+                else:
+                    traffic = ent.get("traffic_bytes_per_launch")
+            except Exception as e:   # a malformed file must not take the line down
+                traffic_note = f"profiles/hbm_traffic.json unreadable: {e}"
+        roofline = {"bound": "hbm", "achieved": gbps(useful), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": gbps(useful) / HBM_PEAK_GBPS, "traffic": traffic,
+                    "kernel": name, "kernel_ms": k_ms, "launch": {"grid": grid, "block": block},
+                    "useful_bytes": useful, "useful_frac": gbps(useful) / HBM_PEAK_GBPS, "top_rows": T_top,
+                    "algorithmic_bytes": alg_bytes,
+                    "by_formula": {"achieved": gbps(alg_bytes), "frac": gbps(alg_bytes) / HBM_PEAK_GBPS,
+                                   "note": f"{row_bytes} B per hit row: every byte of the table, read or not"}}
+        if traffic:
+            roofline["traffic_frac"] = gbps(traffic) / HBM_PEAK_GBPS
+            roofline["traffic_over_useful"] = traffic / useful
+        if traffic_note:
+            roofline["traffic_note"] = traffic_note
+        hpq = cfg["hits_per_query"] if cfg["zipf"] is None else "Zipf" + str(cfg["zipf"])
+        what = (f"{args.config}: {Q_table} queries x {hpq} hits" +
+                (f" per GPU" if scaling == "weak" or world == 1 else f" in ONE table sharded over {world} GPUs (BASELINE config 4)") +
+                f", {tax.n}-taxid synthetic taxonomy, strategy {args.strategy}, taxon {args.taxon}, top group {args.top_group}, "
+                f"layout {LAYOUT_TEXT[args.pident]}")
         line = {
             "metric": "Mqueries/sec consensus (synthetic outfmt-6 hit table)",
             "value": value, "unit": "Mqueries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "i32+f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {Q} queries x "
-                                   f"{cfg['hits_per_query'] if cfg['zipf'] is None else 'Zipf' + str(cfg['zipf'])} hits per GPU, "
-                                   f"{tax.n}-taxid synthetic taxonomy, strategy {args.strategy}, taxon {args.taxon}, "
-                                   f"layout {LAYOUT_TEXT[args.pident]}",
-                       "queries_per_gpu": Q, "hit_rows_per_gpu": Hn, "taxids": tax.n, "strategy": args.strategy,
-                       "taxon": args.taxon, "pident_layout": args.pident, "bytes_per_hit": 24 if args.pident == "f64" else 20, "seed": hex(seed), "generator_version": synth.GENERATOR_VERSION,
-                       "parallelism": f"query-sharded x{world}, taxonomy replicated, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": name, "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes, "bytes_used": used_bytes,
-                         "by_formula": {"achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-                         "launch": {"grid": grid, "block": block}},
+            "config": {"workload": what, "queries_total": total_q, "queries_rank0": Q, "hit_rows_rank0": Hn, "taxids": tax.n,
+                       "strategy": args.strategy, "taxon": args.taxon, "top_group": args.top_group, "pident_layout": args.pident,
+                       "bytes_per_hit": row_bytes, "seed": hex(seed), "generator_version": synth.GENERATOR_VERSION,
+                       "parallelism": f"query-sharded x{world}, taxonomy replicated, no data-path collective",
+                       "process_group": backend},
+            "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
+        if secondary:
+            line["weak_scaling"] = secondary
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

@@ -267,13 +267,32 @@ class SynthHits:
         return (24 if layout == "f64" else 20) * self.n_hits + 8 * (self.n_queries + 1) + 32 * self.n_queries
 
 
+def hit_counts(n_queries: int, seed: int, hits_per_query: Optional[int], zipf: Optional[tuple], device, q_offset: int = 0):
+    """Hits per query (int64 tensor) of queries q_offset .. q_offset + n_queries of the table make_hits generates."""
+    import torch
+    dev = torch.device(device)
+    Q = int(n_queries)
+    if zipf is None:
+        return torch.full((Q,), int(hits_per_query), dtype=torch.int64, device=dev)
+    qi = torch.arange(Q, dtype=torch.int64, device=dev) + int(q_offset)
+    s, lo, hi = zipf
+    thr = torch.from_numpy(_zipf_thresholds(float(s), int(lo), int(hi))).to(dev)
+    u = _h_t(seed, 1, qi) & ((1 << 62) - 1)
+    return torch.searchsorted(thr, u, right=True).clamp_(max=int(hi - lo)) + int(lo)
+
+
 def make_hits(tax: SynthTaxonomy, n_queries: int, seed: int, hits_per_query: Optional[int] = 50,
               zipf: Optional[tuple] = None, device: str = "cpu", p_unmatched: float = 0.0005,
-              chunk_queries: int = 1 << 20, q_offset: int = 0, tables=None, columns: str = "both") -> SynthHits:
+              chunk_queries: int = 1 << 20, q_offset: int = 0, tables=None, columns: str = "both",
+              top_group: str = "geo") -> SynthHits:
     """Hit table in SoA form.  hits_per_query fixed, or zipf=(s, lo, hi) for the skewed config.
 
     q_offset shifts the query counter (rank r of a multi-GPU run generates its own slice of one
     global table).  `tables` caches the device copies of the taxonomy range tables.
+    top_group: size of the top bit-score group — "geo" = 1 + Geometric(0.35) (mean 2.86); "zymo" = the
+    histogram of the reference's one real output (test/mock/output/zymo-mock/blutils.consensus.json: sum of
+    `occurrences` over the 2283 results, mean 5.74, 1.3 % single hits); "all" = every hit of the query ties on the
+    top score (identical database sequences: the table must be read in full).
     """
     import torch
 
@@ -281,13 +300,7 @@ def make_hits(tax: SynthTaxonomy, n_queries: int, seed: int, hits_per_query: Opt
     Q = int(n_queries)
     n_tax = tax.n
     qi = torch.arange(Q, dtype=torch.int64, device=dev) + int(q_offset)
-    if zipf is not None:
-        s, lo, hi = zipf
-        thr = torch.from_numpy(_zipf_thresholds(float(s), int(lo), int(hi))).to(dev)
-        u = _h_t(seed, 1, qi) & ((1 << 62) - 1)
-        nq = torch.searchsorted(thr, u, right=True).clamp_(max=int(hi - lo)) + int(lo)
-    else:
-        nq = torch.full((Q,), int(hits_per_query), dtype=torch.int64, device=dev)
+    nq = hit_counts(Q, seed, hits_per_query, zipf, dev, q_offset)
     seg = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
     torch.cumsum(nq, 0, out=seg[1:])
     H = int(seg[-1].item())
@@ -311,6 +324,12 @@ def make_hits(tax: SynthTaxonomy, n_queries: int, seed: int, hits_per_query: Opt
     # geometric(0.35) top-group size: P(size > j) = 0.65^j, as exact integer thresholds on 2^62
     geo = torch.tensor([int((0.65 ** j) * (1 << 62)) for j in range(1, 64)], dtype=torch.int64, device=dev).flip(0)
     forced = torch.tensor([97000, 99000, 66667, 45500], dtype=torch.int64, device=dev)   # 45.5 is below every cutoff
+    if top_group == "zymo":
+        zsize = torch.tensor(sorted(ZYMO_TOP_GROUPS), dtype=torch.int64, device=dev)
+        zcnt = np.array([ZYMO_TOP_GROUPS[k] for k in sorted(ZYMO_TOP_GROUPS)], dtype=np.float64)
+        zthr = torch.from_numpy(np.minimum((np.cumsum(zcnt) / zcnt.sum() * float(1 << 62)).astype(np.int64), (1 << 62) - 1)).to(dev)
+    elif top_group not in ("geo", "all"):
+        raise ValueError(f"unknown top_group {top_group!r}")
 
     for q0 in range(0, Q, chunk_queries):
         q1 = min(Q, q0 + chunk_queries)
@@ -331,7 +350,12 @@ def make_hits(tax: SynthTaxonomy, n_queries: int, seed: int, hits_per_query: Opt
         lvl = torch.searchsorted(lvl_thr, _h_t(seed, 3, qq) % 1000, right=True)   # 0 = whole table, 1..8 = d..s
         lo = lo_t[lvl, anchor].to(torch.int64)
         hi = hi_t[lvl, anchor].to(torch.int64)
-        gsz = 63 - torch.searchsorted(geo, _h_t(seed, 4, qq) & ((1 << 62) - 1), right=True) + 1
+        if top_group == "geo":
+            gsz = 63 - torch.searchsorted(geo, _h_t(seed, 4, qq) & ((1 << 62) - 1), right=True) + 1
+        elif top_group == "zymo":
+            gsz = zsize[torch.searchsorted(zthr, _h_t(seed, 4, qq) & ((1 << 62) - 1), right=True).clamp_(max=len(zsize) - 1)]
+        else:
+            gsz = n_c.clone()
         gsz = torch.minimum(gsz.clamp_(min=1), n_c)
         B = 200 + _h_t(seed, 5, qq) % 1801
         off = _h_t(seed, 6, qq) % n_c
@@ -362,6 +386,10 @@ def make_hits(tax: SynthTaxonomy, n_queries: int, seed: int, hits_per_query: Opt
         out.align_len[r0:r1] = aln.to(torch.int32)
         out.acc_rank[r0:r1] = torch.where(acc >= (1 << 31), acc - (1 << 32), acc).to(torch.int32)
     return out
+
+
+# sum of consensusBeans[].occurrences per result of the reference's zymo-mock golden output: {top-group size: results}
+ZYMO_TOP_GROUPS = {1: 30, 2: 390, 3: 381, 4: 18, 5: 4, 6: 526, 7: 352, 8: 2, 9: 554, 10: 10, 15: 3, 16: 2, 17: 3, 26: 7, 28: 1}
 
 
 def accession_strings(acc_rank_u32: np.ndarray):

@@ -1,10 +1,12 @@
 #!/bin/bash
 # usage (GPU box, repo root): scripts/ingest_profile.sh r01  -> gpurun_out/ingest_<tag>/: kernel trace of one GPU ingest of a 20 M-row table
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"
 tag=${1:-r01}
-out=gpurun_out/ingest_$tag
-mkdir -p $out
+out="$GRAFT_REPO_ROOT/gpurun_out/ingest_$tag"
+mkdir -p "$out"
+cd "$GRAFT_REPO_ROOT" || exit 1
 python3 scripts/ingest_bench.py --queries 400000 --threads 16 > $out/cpu.txt 2>&1
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 cat > /tmp/ingest_once.py <<PY
 import sys
 sys.path.insert(0, "$GRAFT_REPO_ROOT")

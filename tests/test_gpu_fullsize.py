@@ -23,17 +23,45 @@ def _give_device_memory_back():
     torch.cuda.empty_cache()
 
 
-def test_c3_full_size_properties():
+@pytest.fixture(scope="module")
+def c3_table():
+    """C3 as bench.py builds it: taxonomy, engine handle, the generated columns (both pident encodings) and the
+    desc rows the oracle reads.  Built once for the layouts below."""
     import torch
     cfg = synth.CONFIGS["C3"]
     seed = synth.SEEDS["C3"]
     tax = synth.make_taxonomy(cfg["n_taxa"], seed)
     t = engine.Taxonomy(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, taxon="custom", custom=H.CUSTOM_16S, device=0)
     dh = synth.make_hits(tax, cfg["n_queries"], seed, cfg["hits_per_query"], device="cuda")
-    Q, Hn = dh.n_queries, dh.n_hits
     desc_rows = dh.tax_row.clone()
-    hits = dh.as_dict()
-    hits["tax_row"] = t.engine_rows(desc_rows).contiguous()
+    dh.tax_row = t.engine_rows(desc_rows).contiguous()
+    yield tax, t, dh, desc_rows
+    del dh, desc_rows, t
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _permute_rows(hits, idx):
+    """Rows of every column (or 16-byte side record) gathered by idx; seg_off untouched."""
+    out = {}
+    for k, v in hits.items():
+        if k == "seg_off":
+            out[k] = v
+        elif k == "packed":
+            out[k] = v.view(-1, 4)[idx].contiguous().view(-1)
+        else:
+            out[k] = v[idx].contiguous()
+    return out
+
+
+@pytest.mark.parametrize("layout", ["packed", "f64"])
+def test_c3_full_size_properties(c3_table, layout):
+    """`packed` is the layout bench.py times; `f64` the canonical one of BASELINE.md."""
+    import torch
+    tax, t, dh, desc_rows = c3_table
+    Q, Hn = dh.n_queries, dh.n_hits
+    hits = dh.as_dict(layout)
 
     def run(h, nq):
         out = torch.zeros(32 * nq, dtype=torch.uint8, device="cuda")
@@ -61,7 +89,7 @@ def test_c3_full_size_properties():
     del parts
     # --- permutation equivariance: reverse the order of whole queries (rows inside a query keep file order)
     idx = torch.arange(Hn, device="cuda").view(Q, 50).flip(0).reshape(-1)
-    rev = {k: (v[idx].contiguous() if k != "seg_off" else v) for k, v in hits.items()}
+    rev = _permute_rows(hits, idx)
     got = run(rev, Q)
     exp = whole[::-1].copy()
     has = exp["ref_row"] != 0xFFFFFFFF
@@ -80,6 +108,65 @@ def test_c3_full_size_properties():
                "acc_rank": dh.acc_rank[r0:r1].cpu().numpy()}
         o = H.columnar(tax, sub, "custom", "relaxed", H.CUSTOM_16S, threads=8)
         assert shard.rebase_records(o, r0).tobytes() == whole[q0:q0 + 2500].tobytes()
+
+
+def test_c5_full_size_properties():
+    """BASELINE config 5 at full size: 1 M queries with Zipf(1.1) hit counts 1..5000, 2.4 M deep lineages (depth 25-40),
+    packed layout — stream kernel (short and long pass) and worklist kernel together.  Internal consistency, shard
+    invariance over hit-balanced ranges, and oracle windows chosen so that every one holds worklist queries (> 512 hits)."""
+    import torch
+    cfg = synth.CONFIGS["C5"]
+    seed = synth.SEEDS["C5"]
+    tax = synth.make_taxonomy(cfg["n_taxa"], seed, deep=True)
+    t = engine.Taxonomy(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, taxon="custom", custom=H.CUSTOM_16S, device=0)
+    dh = synth.make_hits(tax, cfg["n_queries"], seed, None, zipf=cfg["zipf"], device="cuda")
+    Q, Hn = dh.n_queries, dh.n_hits
+    desc_rows = dh.tax_row.clone()
+    dh.tax_row = t.engine_rows(desc_rows).contiguous()
+    hits = dh.as_dict("packed")
+    seg = dh.seg_off.cpu().numpy().astype(np.int64)
+    lens = np.diff(seg)
+    assert lens.max() > 4000 and (lens > 512).sum() > 10_000 and t.max_depth >= 25
+
+    def run(h, nq):
+        out = torch.zeros(32 * nq, dtype=torch.uint8, device="cuda")
+        engine.run_consensus_device(t, h, out, strategy="relaxed")
+        torch.cuda.synchronize()
+        return engine.records_from_tensor(out)
+
+    whole = run(hits, Q)
+    st = whole["status"]
+    ok = st <= 1
+    assert ok.mean() > 0.9 and (st == 0).sum() > 300_000 and (st == 1).sum() > 200_000
+    ref = whole["ref_row"][ok].astype(np.int64)
+    qi = np.nonzero(ok)[0]
+    assert ((ref >= seg[qi]) & (ref < seg[qi + 1])).all()                      # the reference row belongs to its query
+    assert (whole["level_mask"][st == 1] != 0).all()
+    assert ((whole["flags"][st == 1] & 1) == 0).all()
+    # --- shard invariance over the hit-balanced ranges of the multi-GPU path (3 ranges: uneven query counts)
+    parts = []
+    for q0, q1 in shard.balanced_query_ranges(seg, 3):
+        sl = {k: v.contiguous() for k, v in shard.slice_table(hits, int(q0), int(q1)).items()}
+        parts.append(shard.rebase_records(run(sl, int(q1 - q0)), int(seg[q0])))
+    assert np.concatenate(parts).tobytes() == whole.tobytes()
+    del parts
+    # --- oracle windows: 24 windows of 1500 queries, each starting at a worklist query (> 512 rows)
+    rng = np.random.default_rng(55)
+    long_q = np.nonzero(lens > 512)[0]
+    long_q = long_q[long_q < Q - 1500]
+    n_work = 0
+    for q0 in rng.choice(long_q, 24, replace=False):
+        q0 = int(q0)
+        q1 = q0 + 1500
+        r0, r1 = int(seg[q0]), int(seg[q1])
+        sub = {"seg_off": seg[q0:q1 + 1] - r0,
+               "bitscore": dh.bitscore[r0:r1].cpu().numpy(), "tax_row": desc_rows[r0:r1].cpu().numpy(),
+               "pident": dh.pident[r0:r1].cpu().numpy(), "align_len": dh.align_len[r0:r1].cpu().numpy(),
+               "acc_rank": dh.acc_rank[r0:r1].cpu().numpy()}
+        o = H.columnar(tax, sub, "custom", "relaxed", H.CUSTOM_16S, threads=8)
+        assert shard.rebase_records(o, r0).tobytes() == whole[q0:q1].tobytes()
+        n_work += int((lens[q0:q1] > 512).sum())
+    assert n_work >= 24 * 100
 
 
 @pytest.mark.parametrize("layout", ["packed", "f64"])
