@@ -28,8 +28,6 @@
 //
 // Integer/compare work only: no MFMA.  HBM-bound: every bit-score is read (4 B/hit), the other 16 B/hit for top rows
 // only, one reference-row line and one 32-byte record per query.
-// BLU_EXP_* macros are timing-only experiment hooks (scripts/build_variants.sh);
-// the product build defines none of them.
 #include <hip/hip_runtime.h>
 
 #include <climits>
@@ -256,11 +254,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Plain (not nt) loads for the five columns: a 128-byte line is shared by consecutive queries (50 hits = 200 B per
 // 4-byte column), and with nt the line is dropped before the wave's next step needs its other half — measured
 // +12 % HBM read requests (TCC_EA0_RDREQ) and +10 % time.
-#ifdef BLU_EXP_NT
-#define STREAM_AUX 2
-#else
 #define STREAM_AUX 0
-#endif
 #ifndef RECORD_AUX
 #define RECORD_AUX 18  // sc1 | nt
 #endif
@@ -297,24 +291,12 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     WaveLds& L = s_lds[wib];
     const uint64_t n_tasks = (h.n_queries + WAVE - 1) / WAVE;
-#ifndef BLU_BLOCK_RECORDS
     const uint64_t wave = (uint64_t)blockIdx.x * WAVES_A + wib;
     const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_A;
 
     for (uint64_t task = wave; task < n_tasks; task += n_waves) {
         const uint64_t q0 = task * WAVE;
         const uint32_t nq = (uint32_t)((h.n_queries - q0) < WAVE ? (h.n_queries - q0) : WAVE);
-#else
-    // The block's waves take CONSECUTIVE tasks and meet at a barrier before their records leave: one
-    // contiguous write burst per block (2 KiB per wave) instead of separate 2 KiB ones.  A record stream of 2.6 % of the
-    // bytes costs the HBM read stream far more than its share when it arrives as small isolated writes
-    // (scripts/probe/pattern_probe.hip: 2 KiB bursts +0.49 ms, 8 KiB +0.23 ms, 32 KiB +0.08 ms on a 1.9 ms stream).
-    const uint64_t n_btasks = (n_tasks + WAVES_A - 1) / WAVES_A;
-    for (uint64_t bt = blockIdx.x; bt < n_btasks; bt += gridDim.x) {
-        const uint64_t task = bt * WAVES_A + wib;
-        const uint64_t q0 = task * WAVE;
-        const uint32_t nq = task < n_tasks ? (uint32_t)((h.n_queries - q0) < WAVE ? (h.n_queries - q0) : WAVE) : 0u;
-#endif
         // lane i holds the row range of query q0 + i
         uint64_t my_off = 0, my_end = 0;
         if ((uint32_t)lane < nq) {
@@ -486,17 +468,12 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             uint32_t idx = T.idx0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#ifdef BLU_EXP_NOLDS
-                if (false) {
-#else
                 if (T.fits && ((T.tmask >> r) & 1u)) {
-#endif
                     put_entry(idx, R, r, sub4 + r);   // the row id carries the lineage length: phase 1 touches no taxonomy table
                     ++idx;
                 }
             }
         };
-#ifndef BLU_EXP_NOPIPE
         if (sparse) {
             // two-stage steps, software-pipelined: while the second-stage requests of iteration i are in flight, the
             // bit-scores of iteration i+1 are requested, so a wave pays one exposed round trip per iteration, not two
@@ -526,14 +503,12 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             }
             return;
         }
-#endif
         for (uint32_t qb = first_q / (QPS * BLU_STEP_SETS) * (QPS * BLU_STEP_SETS); qb < nq; qb += QPS * BLU_STEP_SETS) {
             StepRegs R[BLU_STEP_SETS];
             StepTops T[BLU_STEP_SETS];
             bool all_fit = true;
 #pragma unroll
             for (int u = 0; u < BLU_STEP_SETS; ++u) issue(qb + QPS * u, R[u]);
-#ifndef BLU_EXP_NOREDUCE
             if (sparse) {
 #pragma unroll
                 for (int u = 0; u < BLU_STEP_SETS; ++u) { asm volatile("" ::"v"(R[u].vbs)); tops(R[u], T[u]); all_fit &= T[u].fits; }
@@ -552,7 +527,6 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     emit(R[u], T[u]);
                 }
             }
-#endif
             if (!all_fit) { stop_q = qb + QPS * BLU_STEP_SETS; break; }   // the list is full: the rest of the task in the next round
         }
         };
@@ -658,7 +632,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         // (the steps that do not fit are marked and come again), phase 2a reduces them, the list is reused.  With small
         // top groups (the usual case) everything fits and there is one round; with many ties per query — identical
         // database sequences — a task takes a few rounds instead of sending its queries to the worklist kernel.
-        bool pend = (uint32_t)lane < nq, exp_skip = false;
+        bool pend = (uint32_t)lane < nq;
         uint32_t pend_before = WAVE + 1;
         for (;;) {
         fill = 0;
@@ -698,25 +672,6 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-#ifdef BLU_EXP_NOSTORE
-        exp_skip = true; break;
-#endif
-#ifdef BLU_EXP_P1ONLY
-        {
-            uint4 pa, pb;
-            pack_status(pa, pb, 2, L.list[L.meta[lane] & 0xFF].p0 + L.list[L.meta[lane] & 0xFF].id);
-            __builtin_amdgcn_wave_barrier();
-            uint4* rec = reinterpret_cast<uint4*>(L.list);
-            rec[2 * lane] = pa; rec[2 * lane + 1] = pb;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            uint4* dst = reinterpret_cast<uint4*>(out + q0);
-            for (int half = 0; half < 2; ++half) { const uint32_t c = (uint32_t)lane + 64u * half; if ((c >> 1) < nq) dst[c] = rec[c]; }
-            __builtin_amdgcn_wave_barrier();
-        }
-        exp_skip = true; break;
-#endif
         // ---------------- phase 2a: lane = query, LDS only ----------------
         if (pend) {
             const uint64_t nrows = my_end - my_off;
@@ -778,16 +733,10 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        if (exp_skip) continue;
         if (pend) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;   // a single step larger than the whole list
 
         // ---------------- phase 2c: lane = query, cutoff tests and the record ----------------
-#ifdef BLU_EXP_SKIP_2C
-        if (mode != 3) { pack_status(ra, rb, mode, r_row + minlen + d + r_pos + r_len); rec_kind = 1; }
-        if (false) {
-#else
         if (mode != 3) {
-#endif
             const bool single = mode == 2;
             rec_kind = 1;
             // The reference row: header, neighbour run lengths of 20 levels and the node ids in one 128-byte line (up to 20
@@ -795,11 +744,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             // later, after the codes lookup, fetched the line a second time for half of the queries: the stream had
             // pushed it out of L2 in between.)  Per-level cutoff ids and rank codes come from the row of the shape in
             // the codes table (L2-resident).
-#ifdef BLU_EXP_NOREF
-            const uint32_t* ref = t.lin;
-#else
             const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
-#endif
             const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
             uint4 w[8];
 #pragma unroll
@@ -824,9 +769,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     if (cnt >= BLU_ROW_IV_LEVELS && minlen > BLU_ROW_IV_LEVELS) by_table = true;   // agreement deeper than the row's run lengths
                     else d = umin(minlen, cnt);
                 }
-#ifndef BLU_EXP_NOTAB
                 if (by_table) d = umin(minlen, shared_levels(t, g_lo, g_hi));
-#endif
             }
             const bool agree = single | (d >= minlen);
             if (!agree && d == 0) pack_status(ra, rb, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
@@ -915,7 +858,6 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         // write-through + non-temporal (sc1 nt): a record is written once and never read by the GPU; letting the
         // lines sit dirty in L2 until the read stream evicts them one by one costs ~2x more HBM time (probe:
         // scripts/probe/pattern_probe.hip store modes 1 vs 18)
-#ifndef BLU_BLOCK_RECORDS
         const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + q0), 0, nq * 32u, 0x00020000);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -928,26 +870,6 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-#else
-        __syncthreads();   // all four tasks' records are staged
-        {
-            const uint64_t bq0 = bt * WAVES_A * WAVE;                       // first query of the block's four tasks
-            const uint64_t left = h.n_queries - bq0;
-            const uint32_t bnq = left < WAVES_A * WAVE ? (uint32_t)left : WAVES_A * WAVE;
-            const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + bq0), 0, bnq * 32u, 0x00020000);
-#pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                const uint32_t c = threadIdx.x + BLOCK_A * part;            // 16-byte chunk of the block's 8 KiB
-                const uint32_t w = c >> 7, cc = c & 127u, qc = cc >> 1;      // owning wave, chunk and query inside its task
-                if ((uint64_t)w * WAVE + qc < bnq && s_lds[w].meta[qc]) {
-                    const uint4 v = reinterpret_cast<const uint4*>(s_lds[w].list)[cc];
-                    const u32x4 x = {v.x, v.y, v.z, v.w};
-                    __builtin_amdgcn_raw_buffer_store_b128(x, rs_out, c * 16u, 0, RECORD_AUX);
-                }
-            }
-        }
-        __syncthreads();   // the staging area is the next task's list
-#endif
     }
     // The last block to finish publishes the queue length for the worklist kernel and zeroes the two counters: a run
     // leaves them as it found them — no memset between runs, and a captured graph of the two kernels can be replayed.
