@@ -40,13 +40,15 @@ namespace blu {
 
 #define WAVE 64
 #ifndef BLOCK_A
-#define BLOCK_A 512   // 8 waves = 8 consecutive tasks per block step: 16 KiB record bursts (256: +1.4 % time, 1024: +9 %)
+#define BLOCK_A 768   // 12 waves per CU (three per SIMD): what the per-wave LDS (ring 8 KiB + list) leaves room for
 #endif
 #define WAVES_A (BLOCK_A / WAVE)
 #ifndef LIST_CAP
-#define LIST_CAP 224       // top-group entries per wave task (64 queries; mean ~183, sigma ~18 at geometric(0.35) groups)
+#define LIST_CAP 208       // top-group entries per wave task (64 queries; mean ~183, sigma ~18 at geometric(0.35) groups)
 #endif
-#define ENTRY_BYTES 24
+#ifndef LIST_CAP_F64
+#define LIST_CAP_F64 160   // the same in the f64 layout (4 more bytes per entry): sized so that both layouts keep 12 waves per CU
+#endif
 
 // ---- cross-lane helpers -----------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -214,23 +216,13 @@ __device__ __forceinline__ uint32_t shared_levels(const TaxDev& t, uint32_t lo, 
 // ===============================================================================
 // Kernel A
 // ===============================================================================
-struct Entry {            // one top-group row in LDS, 24 bytes; the first 16 = a side record of the packed layout as it is
-    uint32_t id, p0, aln, acc;    // id = engine row id (sorted position | length << BLU_ROW_BITS); p0: milli-percent pident, or the low f64 word
-    uint32_t pq, p1;              // pq = position in the segment; p1 = high f64 word (f64 layout only)
-};
 template <bool PID32> struct PidKey { typedef double type; };
 template <> struct PidKey<true> { typedef uint32_t type; };
-template <bool PID32>
-__device__ __forceinline__ typename PidKey<PID32>::type entry_pid(const Entry& e) {
-    if constexpr (PID32) return e.p0;
-    else return __hiloint2double((int)e.p1, (int)e.p0);
-}
 template <bool PID32>
 __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
     if constexpr (PID32) return milli_to_f64(k);
     else return k;
 }
-static_assert(sizeof(Entry) == ENTRY_BYTES, "entry layout");
 
 #define META_SLOW 0x80000000u
 #ifndef SHORT_SEG
@@ -259,17 +251,60 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define RECORD_AUX 18  // sc1 | nt
 #endif
 
+// The bit-score stream of a task whose segments are all streamed goes through a per-wave LDS ring, filled by LDS-DMA
+// (buffer_load_dwordx4 ... lds: 1 KiB = 256 rows per wave instruction, no VGPR destination) well ahead of the steps that
+// read it, across task boundaries: a wave no longer pays a memory round trip per step.
+#ifndef RING_ROWS
+#define RING_ROWS 2048u          // power of two, multiple of 256; a step spans up to 1024 + 255 rows
+#endif
+#define RING_PAD 32u              // >= rows one lane scans in a step
+#define RING_CHUNKS (RING_ROWS / 256u)
+#define RING_MASK (RING_ROWS - 1u)
+static_assert((RING_ROWS & RING_MASK) == 0 && RING_ROWS >= 2048u, "ring size");
+static_assert(LIST_CAP >= 128 && LIST_CAP_F64 >= 128, "the list area also stages the 64 records of a task");
+
+template <bool F64>
 struct WaveLds {
-    Entry list[LIST_CAP];       // top-group rows of the task's queries, file order
+    static constexpr uint32_t CAP = F64 ? LIST_CAP_F64 : LIST_CAP;
+    alignas(16) uint32_t ring[RING_ROWS + RING_PAD];   // bit-scores: row v sits at ring[v & RING_MASK]; the pad mirrors ring[0 .. RING_PAD) so that a lane's run of rows never wraps
+    // top-group rows of the task's queries in file order: {engine row id (sorted position | length << BLU_ROW_BITS),
+    // perc_identity (milli-percent, or the low f64 word), align_length, accession rank} — a side record of the packed
+    // layout as it is.  Between phase 1 and the gather of a ring task .x holds the row (relative to the task's first row).
+    uint4 rec[CAP];
+    uint32_t p1[F64 ? CAP : 1];             // high f64 word of perc_identity (f64 layout only)
+    uint16_t pq[CAP];                       // position of the row in its segment
     uint32_t meta[WAVE + 4];    // first entry | k << 16, or META_SLOW
     uint2 seg[WAVE + 4];        // {first row relative to the task's first row, row count (0 if > MAX_TASK_SEG or outside the span)}
 };
+
+// waits until at most k of the wave's vector-memory operations are outstanding (k is wave-uniform; s_waitcnt takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(uint32_t k) {
+    switch (k) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    }
+}
+static_assert(RING_CHUNKS <= 16, "wait_vmcnt covers 0..15 younger chunks");
 
 #ifndef BLU_STEP_SETS
 #define BLU_STEP_SETS 2
 #endif
 #ifndef BLU_WAVES_PER_SIMD
-#define BLU_WAVES_PER_SIMD 4   // 128 VGPRs: two 512-thread blocks per CU
+#define BLU_WAVES_PER_SIMD 3   // one 768-thread block per CU: 168 VGPRs
 #endif
 // LAYOUT: 0 = perc_identity f64 column, 1 = milli-percent u32 column, 2 = packed 16-byte side records
 // {tax_row, pident_milli, align_len, acc_rank} next to the bit-score column
@@ -278,8 +313,9 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                                                                        uint32_t* __restrict__ worklist,
                                                                        uint32_t* __restrict__ work_count) {
     constexpr bool PID32 = LAYOUT != 0, PACKED = LAYOUT == 2;
+    constexpr uint32_t CAP = WaveLds<!PID32>::CAP;   // list entries per wave task
     // work_count = {queue length, blocks done, published length}: the first two are zero on entry and on exit
-    __shared__ WaveLds s_lds[WAVES_A];
+    __shared__ WaveLds<!PID32> s_lds[WAVES_A];
     // the distinct cutoff values of this (taxonomy, backbone): a few hundred doubles, read per level in phase 2c
     __shared__ double s_cut[CUT_LDS];
     const bool cut_in_lds = t.n_cutvals <= CUT_LDS;
@@ -289,22 +325,52 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
     }
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-    WaveLds& L = s_lds[wib];
+    WaveLds<!PID32>& L = s_lds[wib];
     const uint64_t n_tasks = (h.n_queries + WAVE - 1) / WAVE;
     const uint64_t wave = (uint64_t)blockIdx.x * WAVES_A + wib;
     const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_A;
+
+    // ---- the bit-score ring of this wave (see WaveLds).  The table's rows are numbered v = row + mis, where mis (0..3)
+    // makes v = 0 fall on a 16-byte boundary of the column; chunk c = rows 256 c .. 256 c + 255 lands in ring slot
+    // c % RING_CHUNKS whichever task asks for it, so a task finds what the task before it prefetched.
+    const uint32_t mis = (uint32_t)(((uintptr_t)h.bitscore >> 2) & 3u);
+    const char* const bs_al = reinterpret_cast<const char*>(h.bitscore) - 4u * mis;
+    const uint64_t v_total = h.n_hits + mis;
+    uint32_t ring_head = 0, ring_landed = 0, ring_tail = 0;   // chunk ids: next to request / all before it have landed / first still needed
+    uint32_t ring_c0 = 0, ring_end = 0;                        // chunk the DMA descriptor is based at / end of the task's chunks
+    uint64_t pref_task = ~0ull;                                // task whose first chunks were requested ahead
+    __amdgpu_buffer_rsrc_t rs_ring = __builtin_amdgcn_make_buffer_rsrc((void*)bs_al, 0, 0, 0x00020000);
+    auto ring_desc = [&](const uint32_t c0) {                  // descriptor over the chunks from c0 on (at most 2^31 bytes)
+        const uint64_t left = (v_total - ((uint64_t)c0 << 8)) * 4ull;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(bs_al + ((uint64_t)c0 << 10)), 0, left < 0x80000000ull ? (uint32_t)left : 0x80000000u, 0x00020000);
+    };
+    auto ring_dma = [&](const __amdgpu_buffer_rsrc_t rs, const uint32_t c0, const uint32_t c) {   // one chunk: 64 lanes x 16 bytes, no VGPR destination
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(L.ring + (c & (RING_CHUNKS - 1u)) * 256u), 16,
+                                                 (c - c0) * 1024u + (uint32_t)lane * 16u, 0, 0, STREAM_AUX);
+    };
+
+    // The offsets of a task are requested one task ahead (lane i: the row range of query q0 + i), so that their round
+    // trip is never on the critical path and the next task's first chunks can be requested while this one finishes.
+    auto load_seg = [&](const uint64_t tk, uint64_t& o, uint64_t& e) {
+        o = 0; e = 0;
+        if (tk < n_tasks) {
+            const uint64_t q = tk * WAVE + (uint32_t)lane;
+            if (q < h.n_queries) { o = h.seg_off[q]; e = h.seg_off[q + 1]; }
+        }
+    };
+    uint64_t nx_off, nx_end;
+    load_seg(wave, nx_off, nx_end);
 
     for (uint64_t task = wave; task < n_tasks; task += n_waves) {
         const uint64_t q0 = task * WAVE;
         const uint32_t nq = (uint32_t)((h.n_queries - q0) < WAVE ? (h.n_queries - q0) : WAVE);
         // lane i holds the row range of query q0 + i
-        uint64_t my_off = 0, my_end = 0;
-        if ((uint32_t)lane < nq) {
-            my_off = h.seg_off[q0 + lane];
-            my_end = h.seg_off[q0 + lane + 1];
-            if (my_end > h.n_hits) my_end = h.n_hits;   // defend the column reads against a corrupt offset table
-            if (my_off > my_end) my_off = my_end;
-        }
+        uint64_t my_off = nx_off, my_end = nx_end;
+        if (my_end > h.n_hits) my_end = h.n_hits;   // defend the column reads against a corrupt offset table
+        if (my_off > my_end) my_off = my_end;
+        const uint64_t next_task = task + n_waves;
+        load_seg(next_task, nx_off, nx_end);        // consumed after this task's phase 1 (prefetch decision) and by the next iteration
+        asm volatile("" ::: "memory");              // (keeps these loads in front of the ring requests below: the counted waits rely on it)
         uint32_t fill = 0;   // wave-uniform: entries used in the LDS list
         bool in_span = true;
         // One buffer descriptor per column, based at the task's first row and TASK_SPAN rows long: 32-bit lane byte
@@ -329,6 +395,18 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             in_span = my_off >= task_start && (my_end - task_start) <= TASK_SPAN;
             L.seg[lane] = make_uint2((uint32_t)(my_off - task_start), (nrows <= MAX_TASK_SEG && in_span) ? (uint32_t)nrows : 0u);
         }
+        // A task whose queries lie back to back in ascending order, none longer than SHORT_SEG rows, can take its
+        // bit-scores through the ring (lane i: does query i start where query i - 1 ends?)
+        const uint32_t task_rows = (uint32_t)(((uint32_t)lane < nq ? my_end : 0ull) - ((uint32_t)lane < nq ? task_start : 0ull));   // (meaningful in lane nq - 1)
+        bool contiguous;
+        {
+            const uint32_t rel_end = (uint32_t)(my_end - task_start), rel_off = (uint32_t)(my_off - task_start);
+            const uint32_t prev_end = (uint32_t)__shfl_up((int)rel_end, 1);
+            const bool ok = in_span && (my_end - my_off) <= SHORT_SEG && (lane == 0 || rel_off == prev_end);
+            contiguous = __ballot((uint32_t)lane < nq && !ok) == 0ull;
+        }
+        const uint32_t task_nrows = (uint32_t)rl((int)task_rows, (int)nq - 1);   // rows of the whole task (contiguous tasks)
+        const uint64_t vbase = task_start + mis;                                 // v of the task's first row
         // ---------------- phase 1: LPQ lanes per query, 4 consecutive rows per lane, 64 / LPQ queries per step ----------------
         // LPQ is chosen per task from its longest segment: 4 lanes (<= 16 rows: blutils' own default is
         // max_target_seqs = 10), 8 (<= 32), 16 (<= 64), 32 (<= 128) or all 64 lanes (<= 256 rows: BLAST's own default
@@ -366,26 +444,18 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         };
         // row r of the lane as a list entry
         auto put_entry = [&](const uint32_t idx, const StepRegs& R, const int r, const uint32_t pos) {
-            if (PACKED) {   // the loaded record goes to the list as one 16-byte write, the position after it
+            L.pq[idx] = (uint16_t)pos;
+            if (PACKED) {   // the loaded record goes to the list as one 16-byte write
                 const u32x4 rec = r == 0 ? R.vtax : (r == 1 ? R.vp01 : (r == 2 ? R.valn : R.vacc));
-                uint32_t* dst = reinterpret_cast<uint32_t*>(&L.list[idx]);
-                *reinterpret_cast<u32x2*>(dst) = u32x2{rec.x, rec.y};          // (24-byte entries are 8-byte aligned)
-                *reinterpret_cast<u32x2*>(dst + 2) = u32x2{rec.z, rec.w};
-                dst[4] = pos;
+                L.rec[idx] = make_uint4(rec.x, rec.y, rec.z, rec.w);
                 return;
             }
-            Entry e;
-            {
-                const uint32_t xt[4] = {R.vtax.x, R.vtax.y, R.vtax.z, R.vtax.w}, xa[4] = {R.valn.x, R.valn.y, R.valn.z, R.valn.w};
-                const uint32_t xc[4] = {R.vacc.x, R.vacc.y, R.vacc.z, R.vacc.w};
-                const uint32_t xm[4] = {R.vp01.x, R.vp01.y, R.vp01.z, R.vp01.w};   // milli-percent column
-                const uint32_t xlo[4] = {R.vp01.x, R.vp01.z, R.vp23.x, R.vp23.z}, xhi[4] = {R.vp01.y, R.vp01.w, R.vp23.y, R.vp23.w};   // f64 column
-                e.id = xt[r]; e.aln = xa[r]; e.acc = xc[r];
-                e.p0 = PID32 ? xm[r] : xlo[r];
-                e.p1 = PID32 ? 0u : xhi[r];
-            }
-            e.pq = pos;
-            L.list[idx] = e;
+            const uint32_t xt[4] = {R.vtax.x, R.vtax.y, R.vtax.z, R.vtax.w}, xa[4] = {R.valn.x, R.valn.y, R.valn.z, R.valn.w};
+            const uint32_t xc[4] = {R.vacc.x, R.vacc.y, R.vacc.z, R.vacc.w};
+            const uint32_t xm[4] = {R.vp01.x, R.vp01.y, R.vp01.z, R.vp01.w};   // milli-percent column
+            const uint32_t xlo[4] = {R.vp01.x, R.vp01.z, R.vp23.x, R.vp23.z}, xhi[4] = {R.vp01.y, R.vp01.w, R.vp23.y, R.vp23.w};   // f64 column
+            L.rec[idx] = make_uint4(xt[r], PID32 ? xm[r] : xlo[r], xa[r], xc[r]);
+            if (!PID32) L.p1[idx] = xhi[r];
         };
         uint32_t stop_q = WAVE;      // first query index phase 1 did not get to in this round (the list was full), or 64
         uint32_t short_seg = SHORT_SEG;   // longest segment the streamed pass takes in this round (longer ones: the long pass)
@@ -442,7 +512,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             incl += (uint32_t)dpp<0x118>((int)incl);
             const uint32_t k0 = (uint32_t)rl((int)incl, 15), k1 = (uint32_t)rl((int)incl, 31);
             const uint32_t k2 = (uint32_t)rl((int)incl, 47), k3 = (uint32_t)rl((int)incl, 63);
-            const bool fits = fill + k0 + k1 + k2 + k3 <= LIST_CAP;   // else: the queries of this step go to the worklist
+            const bool fits = fill + k0 + k1 + k2 + k3 <= CAP;   // else: the queries of this step go to the worklist
             const uint32_t p1 = fill + k0, p2 = p1 + k1, p3 = p2 + k2;
             const uint32_t rbase = row16 == 0 ? fill : (row16 == 1 ? p1 : (row16 == 2 ? p2 : p3));   // list slot where this 16-lane row starts
             uint32_t gk;                                          // top rows of this lane's query
@@ -587,7 +657,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     slot[hf] = (row16 == 0 ? 0u : (row16 == 1 ? k0 : (row16 == 2 ? k0 + k1 : k0 + k1 + k2))) + in - c[hf];
                 }
                 const uint32_t gk = tot[0] + tot[1];
-                const bool fits = fill + gk <= LIST_CAP;
+                const bool fits = fill + gk <= CAP;
                 if (lane == 0) {
                     if (halves) L.meta[qi] = fits ? (fill | (gk << 16)) : META_SLOW;
                     else {
@@ -619,6 +689,126 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 }
             }
         };
+        // ---------------- phase 1 of a ring task: lane = RPL consecutive rows, read from the LDS ring ----------------
+        // A step takes 64 / LPQ queries, LPQ = 1, 2, 4 or 8 lanes per query by the task's longest segment (<= 16 RPL / 8 = 128
+        // rows); a lane scans its rows one after the other — the bit-scores are in LDS, so a per-lane address costs
+        // nothing — and only the maximum and the counts cross lanes: a quarter of the vector instructions of the
+        // four-rows-per-lane steps above.  Top rows go to the list as ROW INDICES; their 16 other bytes are gathered
+        // afterwards, one list entry per lane (gather_list).
+        auto ring_mark_landed = [&](const uint32_t upto) {      // chunks below `upto` have landed; keeps the pad a mirror of ring[0 .. RING_PAD)
+            const uint32_t m0 = (ring_landed + RING_CHUNKS - 1u) & ~(RING_CHUNKS - 1u);   // first slot-0 chunk not yet marked
+            if (m0 < upto) {
+                if ((uint32_t)lane < RING_PAD) L.ring[RING_ROWS + lane] = L.ring[lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            ring_landed = upto;
+        };
+        auto ring_refill = [&]() {                              // request what the ring has room for, in chunk order
+            if (ring_head < ring_tail) { ring_head = ring_tail; if (ring_landed < ring_tail) ring_landed = ring_tail; }
+            while (ring_head < ring_end && ring_head - ring_tail < RING_CHUNKS) { ring_dma(rs_ring, ring_c0, ring_head); ++ring_head; }
+        };
+        auto phase1_scan = [&](const auto rpl_c, const uint32_t LPQ) {
+            constexpr uint32_t RPL = decltype(rpl_c)::value;
+            static_assert(RPL <= RING_PAD && RPL <= 32u, "rows per lane");
+            const uint32_t QPS = WAVE / LPQ;
+            const uint32_t grp = (uint32_t)lane / LPQ, sub = ((uint32_t)lane & (LPQ - 1u)) * RPL, row16 = (uint32_t)lane >> 4;
+            for (uint32_t qb = first_q / QPS * QPS; qb < nq; qb += QPS) {
+                // the rows of this step lie back to back: [first row of query qb, first row of query qb + QPS)
+                const uint32_t r_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.seg[qb < first_q ? first_q : qb].x);   // (queries before first_q are done)
+                const uint32_t qn = qb + QPS;
+                const uint32_t r_hi = qn < nq ? (uint32_t)__builtin_amdgcn_readfirstlane((int)L.seg[qn].x) : task_nrows;
+                ring_tail = (uint32_t)((vbase + r_lo) >> 8);
+                ring_refill();
+                if (r_hi > r_lo) {
+                    const uint32_t need = (uint32_t)((vbase + r_hi - 1u) >> 8);
+                    if (need >= ring_landed) { wait_vmcnt(ring_head - 1u - need); ring_mark_landed(need + 1u); }   // all but the chunks requested after `need`
+                }
+                const uint32_t qi = qb + grp;
+                const uint2 sg = L.seg[qi];
+                const int left = (sg.y > short_seg ? 0 : (int)sg.y) - (int)sub;      // rows of the segment from this lane's first row on
+                const uint32_t row0 = sg.x + sub;
+                const uint32_t a = ((uint32_t)vbase + row0) & RING_MASK;
+                int b[RPL];
+#pragma unroll
+                for (uint32_t i = 0; i < RPL; ++i) b[i] = (int)L.ring[a + i];
+                int M = INT_MIN;
+#pragma unroll
+                for (uint32_t i = 0; i < RPL; ++i) { b[i] = (int)i < left ? b[i] : INT_MIN; M = imax(M, b[i]); }
+                if (LPQ >= 2) M = imax(M, dpp<0xB1>(M));
+                if (LPQ >= 4) M = imax(M, dpp<0x4E>(M));
+                if (LPQ >= 8) M = imax(M, dpp<0x141>(M));             // row_half_mirror
+                uint32_t mask = 0;                                    // bit RPL - 1 - i = row i ties on the query's top score
+#pragma unroll
+                for (uint32_t i = 0; i < RPL; ++i) mask = (mask << 1) | (uint32_t)(b[i] == M);
+                mask = left > 0 ? mask : 0u;
+                const uint32_t c = (uint32_t)__builtin_popcount(mask);
+                uint32_t incl = c;                                    // inclusive prefix of the top-row counts inside the 16-lane row
+                incl += (uint32_t)dpp<0x111>((int)incl);
+                incl += (uint32_t)dpp<0x112>((int)incl);
+                incl += (uint32_t)dpp<0x114>((int)incl);
+                incl += (uint32_t)dpp<0x118>((int)incl);
+                const uint32_t k0 = (uint32_t)rl((int)incl, 15), k1 = (uint32_t)rl((int)incl, 31);
+                const uint32_t k2 = (uint32_t)rl((int)incl, 47), k3 = (uint32_t)rl((int)incl, 63);
+                const bool fits = fill + k0 + k1 + k2 + k3 <= CAP;
+                const uint32_t p1 = fill + k0, p2 = p1 + k1, p3 = p2 + k2;
+                const uint32_t rbase = row16 == 0 ? fill : (row16 == 1 ? p1 : (row16 == 2 ? p2 : p3));
+                uint32_t gk = c;                                      // top rows of this lane's query
+                if (LPQ >= 2) gk += (uint32_t)dpp<0xB1>((int)gk);
+                if (LPQ >= 4) gk += (uint32_t)dpp<0x4E>((int)gk);
+                if (LPQ >= 8) gk += (uint32_t)dpp<0x141>((int)gk);
+                uint32_t idx = rbase + incl - c;                      // list slot of this lane's first top row (file order)
+                if (sub == 0) L.meta[qi] = fits ? (idx | (gk << 16)) : META_SLOW;
+                if (!fits) { stop_q = qn; break; }                    // the list is full: the rest of the task in the next round
+                fill = p3 + k3;
+                uint32_t m = mask;
+                while (__ballot(m != 0u)) {
+                    if (m) {
+                        const uint32_t hb = 31u - (uint32_t)__builtin_clz(m), i = RPL - 1u - hb;
+                        L.rec[idx].x = row0 + i;                      // the row, relative to the task's first row: gather_list turns it into the side record
+                        L.pq[idx] = (uint16_t)(sub + i);
+                        ++idx;
+                        m &= ~(1u << hb);
+                    }
+                }
+            }
+        };
+        // the 16 other bytes of the list's rows: one entry per lane, every load of the round in flight before the first is used
+        auto gather_list = [&](auto&& between) {
+            constexpr int NG = (CAP + WAVE - 1) / WAVE;
+            u32x4 g[NG];
+            uint32_t ghi[NG];
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const uint32_t idx = (uint32_t)u * WAVE + (uint32_t)lane;
+                const bool valid = idx < fill;
+                const uint32_t row = valid ? L.rec[idx < CAP ? idx : 0u].x : 0u;
+                g[u] = u32x4{0u, 0u, 0u, 0u}; ghi[u] = 0u;
+                if ((uint32_t)u * WAVE >= fill) continue;             // (wave-uniform)
+                if (PACKED) g[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, valid ? row * 16u : 0xFFFFFFC0u, 0, STREAM_AUX);
+                else {
+                    const uint32_t o4 = valid ? row * 4u : 0xFFFFFFF0u;
+                    g[u].x = __builtin_amdgcn_raw_buffer_load_b32(rs_tax, o4, 0, STREAM_AUX);
+                    if (PID32) g[u].y = __builtin_amdgcn_raw_buffer_load_b32(rs_pid, o4, 0, STREAM_AUX);
+                    else {
+                        const u32x2 p = __builtin_amdgcn_raw_buffer_load_b64(rs_pid, valid ? row * 8u : 0xFFFFFFE0u, 0, STREAM_AUX);
+                        g[u].y = p.x; ghi[u] = p.y;
+                    }
+                    g[u].z = __builtin_amdgcn_raw_buffer_load_b32(rs_aln, o4, 0, STREAM_AUX);
+                    g[u].w = __builtin_amdgcn_raw_buffer_load_b32(rs_acc, o4, 0, STREAM_AUX);
+                }
+            }
+            between();
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const uint32_t idx = (uint32_t)u * WAVE + (uint32_t)lane;
+                if (idx < fill) {
+                    L.rec[idx] = make_uint4(g[u].x, g[u].y, g[u].z, g[u].w);
+                    if (!PID32) L.p1[idx] = ghi[u];
+                }
+            }
+        };
         // per-lane (= per-query) results of phase 2a
         // mode: 0 multi, 2 single, 3 finished (empty / error / handed to the worklist)
         const uint64_t q = q0 + (uint32_t)lane;
@@ -634,9 +824,17 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         // database sequences — a task takes a few rounds instead of sending its queries to the worklist kernel.
         bool pend = (uint32_t)lane < nq;
         uint32_t pend_before = WAVE + 1;
+        if (contiguous) {                                            // this task's chunks; what the task before requested ahead stays
+            ring_c0 = (uint32_t)(vbase >> 8);
+            rs_ring = ring_desc(ring_c0);
+            ring_end = task_nrows ? (uint32_t)((vbase + task_nrows - 1u) >> 8) + 1u : ring_c0;
+            if (pref_task != task) ring_head = ring_landed = ring_c0;
+            ring_tail = ring_c0;
+        }
         for (;;) {
         fill = 0;
         stop_q = WAVE;
+        bool ring_round = false;
         {
             const uint32_t rows = L.seg[lane].y;                    // this lane's query (0: empty, done, too long, or outside the span)
             const uint64_t live = __ballot(rows != 0u);
@@ -661,13 +859,51 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             }
 #endif
             const uint32_t longest = wave_max_u32(rows > short_seg ? 0u : rows);   // longest streamed segment of the task
-            if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>(), false);   // the C3 shape, specialised
+            ring_round = contiguous && longest != 0u && __ballot(rows > short_seg) == 0ull;
+            if (ring_round) phase1_scan(std::integral_constant<uint32_t, 16>(), longest <= 16u ? 1u : (longest <= 32u ? 2u : (longest <= 64u ? 4u : 8u)));
+            else if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>(), false);   // the C3 shape, specialised
             else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u), longest >= (PACKED ? 9u : 25u));   // two-stage steps: measured break-even (packed records: 10 hits -2.5 %, 20 hits -17 %; columns: 20 hits +3 %, 30 hits -6 %)
             // queries phase 1 did not get to (the list filled up): marked for the next round, long ones included
             if (stop_q < WAVE && rows != 0u && ((uint32_t)lane >= stop_q || rows > short_seg)) L.meta[lane] = META_SLOW;
             const uint64_t long_mask = __ballot(rows > short_seg);
             if (long_mask && stop_q == WAVE) phase1_long(long_mask);   // after the streamed pass: it overwrites their (empty) list heads
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // Last round of the task (nothing left pending): the ring is free, so the first chunks of the NEXT task are
+        // requested now and travel while this task finishes (its offsets were requested when this task began).
+        const bool last_round = __ballot(pend && (my_end - my_off) != 0ull && (my_end - my_off) <= MAX_TASK_SEG && in_span && (L.meta[lane] & META_SLOW)) == 0ull;
+        uint32_t nxt_c0 = 0, nxt_lim = 0;
+        if (last_round && next_task < n_tasks) {
+            uint64_t n_off = nx_off, n_end = nx_end;
+            if (n_end > h.n_hits) n_end = h.n_hits;
+            if (n_off > n_end) n_off = n_end;
+            const uint64_t nq0 = next_task * WAVE;
+            const uint32_t nqn = (uint32_t)((h.n_queries - nq0) < WAVE ? (h.n_queries - nq0) : WAVE);
+            const uint64_t n_start = rl_u64(n_off, 0);
+            const bool n_span = n_off >= n_start && (n_end - n_start) <= TASK_SPAN;
+            const uint32_t rel_end = (uint32_t)(n_end - n_start), rel_off = (uint32_t)(n_off - n_start);
+            const uint32_t prev_end = (uint32_t)__shfl_up((int)rel_end, 1);
+            const bool ok = n_span && (n_end - n_off) <= SHORT_SEG && (lane == 0 || rel_off == prev_end);
+            const uint32_t n_rows = (uint32_t)rl((int)rel_end, (int)nqn - 1);
+            if (__ballot((uint32_t)lane < nqn && !ok) == 0ull && n_rows != 0u) {
+                const uint64_t vb = n_start + mis;
+                nxt_c0 = (uint32_t)(vb >> 8);
+                const uint32_t cend = (uint32_t)((vb + n_rows - 1u) >> 8) + 1u;
+                nxt_lim = cend < nxt_c0 + RING_CHUNKS ? cend : nxt_c0 + RING_CHUNKS;
+            }
+        }
+        auto prefetch_next = [&]() {
+            if (nxt_lim > nxt_c0) {
+                const auto rsn = ring_desc(nxt_c0);
+                for (uint32_t c = nxt_c0; c < nxt_lim; ++c) ring_dma(rsn, nxt_c0, c);
+                ring_head = nxt_lim; ring_landed = nxt_c0; ring_tail = nxt_c0;
+                pref_task = next_task;
+            }
+        };
+        if (ring_round) gather_list(prefetch_next);
+        else prefetch_next();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -685,16 +921,16 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 // parse errors first, in file order (find_single_query_consensus.rs:51-64), then NaN pident
                 uint32_t err = 0, err_pos = 0;
                 for (uint32_t e = 0; e < k; ++e) {
-                    const uint32_t id = L.list[first + e].id;
+                    const uint32_t id = L.rec[first + e].x;
                     if (err == 0 && ((id & ROW_MASK) >= t.n_tax || (id >> BLU_ROW_BITS) == 0)) {
                         err = (id & ROW_MASK) >= t.n_tax ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE;
-                        err_pos = L.list[first + e].pq;
+                        err_pos = L.pq[first + e];
                     }
                 }
                 if (!PID32 && err == 0)
                     for (uint32_t e = 0; e < k; ++e) {
-                        const double p = __hiloint2double((int)L.list[first + e].p1, (int)L.list[first + e].p0);
-                        if (err == 0 && p != p) { err = BLU_ST_ERR_BAD_PIDENT; err_pos = L.list[first + e].pq; }
+                        const double p = __hiloint2double((int)L.p1[first + e], (int)L.rec[first + e].y);
+                        if (err == 0 && p != p) { err = BLU_ST_ERR_BAD_PIDENT; err_pos = L.pq[first + e]; }
                     }
                 if (err) { pack_status(ra, rb, err, row0 + err_pos); rec_kind = 1; }
                 else {
@@ -704,21 +940,23 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     int b_aln = 0;
                     minlen = 0xFFFFFFFFu;
                     for (uint32_t e = 0; e < k; ++e) {
-                        const Entry x = L.list[first + e];
-                        const uint32_t len = umin(x.id >> BLU_ROW_BITS, t.max_depth), pos = x.id & ROW_MASK;
+                        const uint4 x = L.rec[first + e];       // {row id, pident, align_len, accession rank}
+                        const uint32_t len = umin(x.x >> BLU_ROW_BITS, t.max_depth), pos = x.x & ROW_MASK;
                         minlen = umin(minlen, len);
                         lo = umin(lo, pos);
                         hi = pos > hi ? pos : hi;
-                        const PK xpid = entry_pid<PID32>(x);
+                        PK xpid;
+                        if constexpr (PID32) xpid = x.y;
+                        else xpid = __hiloint2double((int)L.p1[first + e], (int)x.y);
                         max_pid = xpid > max_pid ? xpid : max_pid;
-                        const bool take = (e == 0) | key_better<STRAT, PK>(len, xpid, (int)x.aln, x.acc, b_len, r_pid, b_aln, b_acc);
+                        const bool take = (e == 0) | key_better<STRAT, PK>(len, xpid, (int)x.z, x.w, b_len, r_pid, b_aln, b_acc);
                         b_len = take ? len : b_len;
                         r_len = b_len;
                         r_pid = take ? xpid : r_pid;
-                        b_aln = take ? (int)x.aln : b_aln;
-                        b_acc = take ? x.acc : b_acc;
+                        b_aln = take ? (int)x.z : b_aln;
+                        b_acc = take ? x.w : b_acc;
                         r_row = take ? pos : r_row;
-                        r_pos = take ? x.pq : r_pos;
+                        r_pos = take ? (uint32_t)L.pq[first + e] : r_pos;
                     }
                     mode = k == 1 ? 2u : 0u;
                     g_lo = lo; g_hi = hi;    // span of the group in sorted order: phase 2c turns it into the shared levels
@@ -843,12 +1081,14 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 }
             }
         }
+        // what was requested ahead for the next task has to be in the ring before that task counts its own requests
+        if (ring_landed < ring_head) { wait_vmcnt(0u); ring_mark_landed(ring_head); }
         // ---------------- records: staged through LDS, stored as two fully coalesced 1 KiB rows ----------------
         // (a 32-byte record per lane straight to memory is 64 scattered 16-byte pieces per store instruction;
         // measured: 0.7 ms of a 2.7 ms launch.)  The list area is dead after phase 2a and is reused.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        uint4* rec = reinterpret_cast<uint4*>(L.list);
+        uint4* rec = L.rec;
         rec[2 * lane] = ra;
         rec[2 * lane + 1] = rb;
         L.meta[lane] = rec_kind;

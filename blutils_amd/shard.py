@@ -30,7 +30,8 @@ def slice_table(hits: dict, q0: int, q1: int) -> dict:
     """The rows of queries [q0, q1) with offsets rebased to 0 (numpy arrays or torch tensors)."""
     seg = hits["seg_off"]
     r0, r1 = int(seg[q0]), int(seg[q1])
-    out = {k: v[r0:r1] for k, v in hits.items() if k != "seg_off"}
+    # (the packed layout holds four words per hit row: {tax_row, pident_milli, align_len, acc_rank})
+    out = {k: (v[4 * r0:4 * r1] if k == "packed" else v[r0:r1]) for k, v in hits.items() if k != "seg_off"}
     out["seg_off"] = seg[q0:q1 + 1] - seg[q0]
     return out
 
