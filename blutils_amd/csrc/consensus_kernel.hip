@@ -38,6 +38,49 @@
 
 namespace blu {
 
+// Timing-only switches for attributing time / instruction counts to the phases of the stream kernel (make exp
+// FLAGS="-DBLU_EXPERIMENTS -DBLU_X_...=true"): they produce WRONG records.  The product build leaves them all false and
+// the compiler drops the tests.
+#ifndef BLU_EXPERIMENTS
+#define BLU_X_SKIP_2A false
+#define BLU_X_SKIP_2C false
+#define BLU_X_SKIP_RUNLEN false
+#define BLU_X_SKIP_LEVELS false
+#define BLU_X_SKIP_GATHER false
+#define BLU_X_SCAN_MIN false
+#else
+#ifndef BLU_X_SCAN_MIN
+#define BLU_X_SCAN_MIN false
+#endif
+#ifndef BLU_X_SKIP_2A
+#define BLU_X_SKIP_2A false
+#endif
+#ifndef BLU_X_SKIP_2C
+#define BLU_X_SKIP_2C false
+#endif
+#ifndef BLU_X_SKIP_RUNLEN
+#define BLU_X_SKIP_RUNLEN false
+#endif
+#ifndef BLU_X_SKIP_LEVELS
+#define BLU_X_SKIP_LEVELS false
+#endif
+#ifndef BLU_X_SKIP_GATHER
+#define BLU_X_SKIP_GATHER false
+#endif
+#endif
+
+// In-kernel stamps (experiment builds only: -DBLU_EXPERIMENTS -DBLU_X_STAMPS): s_memtime at the phase boundaries of the
+// stream kernel, summed per wave and written over the first records of `out` when the wave is done (scripts/stamps.py).
+#if defined(BLU_EXPERIMENTS) && defined(BLU_X_STAMPS)
+#define STAMP_DECL uint64_t st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { const uint64_t st_now = __builtin_amdgcn_s_memtime(); st_sum[i] += st_now - st_prev; st_prev = st_now; }
+#define STAMP_DRAIN asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_DRAIN
+#endif
+
 #define WAVE 64
 #ifndef BLOCK_A
 #define BLOCK_A 768   // 12 waves per CU (three per SIMD): what the per-wave LDS (ring 8 KiB + list) leaves room for
@@ -339,14 +382,26 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
     uint32_t ring_head = 0, ring_landed = 0, ring_tail = 0;   // chunk ids: next to request / all before it have landed / first still needed
     uint32_t ring_c0 = 0, ring_end = 0;                        // chunk the DMA descriptor is based at / end of the task's chunks
     uint64_t pref_task = ~0ull;                                // task whose first chunks were requested ahead
-    __amdgpu_buffer_rsrc_t rs_ring = __builtin_amdgcn_make_buffer_rsrc((void*)bs_al, 0, 0, 0x00020000);
-    auto ring_desc = [&](const uint32_t c0) {                  // descriptor over the chunks from c0 on (at most 2^31 bytes)
+    // The DMA is issued as inline assembly (m0 = LDS address of the slot; buffer_load_dwordx4 ... lds) rather than through
+    // __builtin_amdgcn_raw_ptr_buffer_load_lds: with the builtin hipcc puts an s_waitcnt vmcnt(0) in front of every LDS
+    // read that follows (any LDS access may alias a pending LDS-DMA in its book-keeping), which drains the requests this
+    // ring exists to keep in flight.  The waits for ring data are the explicit wait_vmcnt() calls; the compiler's own
+    // vmcnt counts for ordinary loads do not know about these requests and are therefore only ever too strict.
+    u32x4 rs_ring = {0u, 0u, 0u, 0x00020000u};
+    auto ring_desc = [&](const uint32_t c0) {                  // buffer descriptor over the chunks from c0 on (at most 2^31 bytes)
         const uint64_t left = (v_total - ((uint64_t)c0 << 8)) * 4ull;
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(bs_al + ((uint64_t)c0 << 10)), 0, left < 0x80000000ull ? (uint32_t)left : 0x80000000u, 0x00020000);
+        const uint64_t base = (uint64_t)(uintptr_t)bs_al + ((uint64_t)c0 << 10);
+        return u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base),
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(base >> 32) & 0xFFFFu)),
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(left < 0x80000000ull ? (uint32_t)left : 0x80000000u)), 0x00020000u};
     };
-    auto ring_dma = [&](const __amdgpu_buffer_rsrc_t rs, const uint32_t c0, const uint32_t c) {   // one chunk: 64 lanes x 16 bytes, no VGPR destination
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(L.ring + (c & (RING_CHUNKS - 1u)) * 256u), 16,
-                                                 (c - c0) * 1024u + (uint32_t)lane * 16u, 0, 0, STREAM_AUX);
+    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)L.ring);
+    auto ring_dma = [&](const u32x4 rs, const uint32_t c0, const uint32_t c) {   // one chunk: 64 lanes x 16 bytes, no VGPR destination
+        const uint32_t dst = ring_lds + (c & (RING_CHUNKS - 1u)) * 1024u;
+        const uint32_t voff = (c - c0) * 1024u + (uint32_t)lane * 16u;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs) : "memory");
     };
 
     // The offsets of a task are requested one task ahead (lane i: the row range of query q0 + i), so that their round
@@ -360,6 +415,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
     };
     uint64_t nx_off, nx_end;
     load_seg(wave, nx_off, nx_end);
+    STAMP_DECL
 
     for (uint64_t task = wave; task < n_tasks; task += n_waves) {
         const uint64_t q0 = task * WAVE;
@@ -406,6 +462,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             contiguous = __ballot((uint32_t)lane < nq && !ok) == 0ull;
         }
         const uint32_t task_nrows = (uint32_t)rl((int)task_rows, (int)nq - 1);   // rows of the whole task (contiguous tasks)
+        const uint32_t seg_x = (uint32_t)(my_off - task_start);                  // lane i: first row of query i, relative to the task
         const uint64_t vbase = task_start + mis;                                 // v of the task's first row
         // ---------------- phase 1: LPQ lanes per query, 4 consecutive rows per lane, 64 / LPQ queries per step ----------------
         // LPQ is chosen per task from its longest segment: 4 lanes (<= 16 rows: blutils' own default is
@@ -716,15 +773,17 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             const uint32_t grp = (uint32_t)lane / LPQ, sub = ((uint32_t)lane & (LPQ - 1u)) * RPL, row16 = (uint32_t)lane >> 4;
             for (uint32_t qb = first_q / QPS * QPS; qb < nq; qb += QPS) {
                 // the rows of this step lie back to back: [first row of query qb, first row of query qb + QPS)
-                const uint32_t r_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.seg[qb < first_q ? first_q : qb].x);   // (queries before first_q are done)
+                const uint32_t r_lo = (uint32_t)rl((int)seg_x, (int)(qb < first_q ? first_q : qb));   // (queries before first_q are done)
                 const uint32_t qn = qb + QPS;
-                const uint32_t r_hi = qn < nq ? (uint32_t)__builtin_amdgcn_readfirstlane((int)L.seg[qn].x) : task_nrows;
+                const uint32_t r_hi = qn < nq ? (uint32_t)rl((int)seg_x, (int)qn) : task_nrows;
+                STAMP(1)
                 ring_tail = (uint32_t)((vbase + r_lo) >> 8);
                 ring_refill();
                 if (r_hi > r_lo) {
                     const uint32_t need = (uint32_t)((vbase + r_hi - 1u) >> 8);
                     if (need >= ring_landed) { wait_vmcnt(ring_head - 1u - need); ring_mark_landed(need + 1u); }   // all but the chunks requested after `need`
                 }
+                STAMP(10)   // (waiting for ring data)
                 const uint32_t qi = qb + grp;
                 const uint2 sg = L.seg[qi];
                 const int left = (sg.y > short_seg ? 0 : (int)sg.y) - (int)sub;      // rows of the segment from this lane's first row on
@@ -733,12 +792,19 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 int b[RPL];
 #pragma unroll
                 for (uint32_t i = 0; i < RPL; ++i) b[i] = (int)L.ring[a + i];
+                // the step's rows are in registers: its chunks can be overwritten, so what follows is requested now — two
+                // steps ahead of the step that reads it (the DMA writes LDS: not before the reads above have returned)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (uint32_t i = 0; i < RPL; ++i) asm volatile("" : "+v"(b[i]));
+                if (r_hi > r_lo) { ring_tail = (uint32_t)((vbase + r_hi) >> 8); ring_refill(); }
                 int M = INT_MIN;
 #pragma unroll
                 for (uint32_t i = 0; i < RPL; ++i) { b[i] = (int)i < left ? b[i] : INT_MIN; M = imax(M, b[i]); }
                 if (LPQ >= 2) M = imax(M, dpp<0xB1>(M));
                 if (LPQ >= 4) M = imax(M, dpp<0x4E>(M));
                 if (LPQ >= 8) M = imax(M, dpp<0x141>(M));             // row_half_mirror
+                if (BLU_X_SCAN_MIN) { if (sub == 0) L.meta[qi] = (uint32_t)M & 0xFFu; continue; }
                 uint32_t mask = 0;                                    // bit RPL - 1 - i = row i ties on the query's top score
 #pragma unroll
                 for (uint32_t i = 0; i < RPL; ++i) mask = (mask << 1) | (uint32_t)(b[i] == M);
@@ -760,8 +826,14 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 if (LPQ >= 8) gk += (uint32_t)dpp<0x141>((int)gk);
                 uint32_t idx = rbase + incl - c;                      // list slot of this lane's first top row (file order)
                 if (sub == 0) L.meta[qi] = fits ? (idx | (gk << 16)) : META_SLOW;
-                if (!fits) { stop_q = qn; break; }                    // the list is full: the rest of the task in the next round
+                if (!fits) {                                          // the list is full: the rest of the task in the next round,
+                    stop_q = qn;                                      // which reads this step's rows again — their chunks were given
+                    wait_vmcnt(0u);                                   // back above, so the ring starts over at the step's first row
+                    ring_head = ring_landed = ring_tail = (uint32_t)((vbase + r_lo) >> 8);
+                    break;
+                }
                 fill = p3 + k3;
+                STAMP(1)
                 uint32_t m = mask;
                 while (__ballot(m != 0u)) {
                     if (m) {
@@ -772,6 +844,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                         m &= ~(1u << hb);
                     }
                 }
+                STAMP(11)   // (writing the list)
             }
         };
         // the 16 other bytes of the list's rows: one entry per lane, every load of the round in flight before the first is used
@@ -831,6 +904,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             if (pref_task != task) ring_head = ring_landed = ring_c0;
             ring_tail = ring_c0;
         }
+        STAMP(0)   // task set-up: offsets, descriptors, contiguity
         for (;;) {
         fill = 0;
         stop_q = WAVE;
@@ -871,12 +945,17 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        STAMP(1)   // phase 1
         // Last round of the task (nothing left pending): the ring is free, so the first chunks of the NEXT task are
         // requested now and travel while this task finishes (its offsets were requested when this task began).
         const bool last_round = __ballot(pend && (my_end - my_off) != 0ull && (my_end - my_off) <= MAX_TASK_SEG && in_span && (L.meta[lane] & META_SLOW)) == 0ull;
         uint32_t nxt_c0 = 0, nxt_lim = 0;
         if (last_round && next_task < n_tasks) {
-            uint64_t n_off = nx_off, n_end = nx_end;
+            // (opaque to the optimizer: otherwise what follows is hoisted out of the rounds loop to right behind the load and
+            // the task would start by waiting for the next task's offsets)
+            uint32_t o_lo = (uint32_t)nx_off, o_hi = (uint32_t)(nx_off >> 32), e_lo = (uint32_t)nx_end, e_hi = (uint32_t)(nx_end >> 32);
+            asm volatile("" : "+v"(o_lo), "+v"(o_hi), "+v"(e_lo), "+v"(e_hi));
+            uint64_t n_off = ((uint64_t)o_hi << 32) | o_lo, n_end = ((uint64_t)e_hi << 32) | e_lo;
             if (n_end > h.n_hits) n_end = h.n_hits;
             if (n_off > n_end) n_off = n_end;
             const uint64_t nq0 = next_task * WAVE;
@@ -902,68 +981,75 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 pref_task = next_task;
             }
         };
-        if (ring_round) gather_list(prefetch_next);
+        if (ring_round && !BLU_X_SKIP_GATHER) gather_list(prefetch_next);
         else prefetch_next();
+        STAMP(2)   // next-task decision, gather issue + wait + list write
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
         // ---------------- phase 2a: lane = query, LDS only ----------------
-        if (pend) {
+        // One pass over the list entries of every query at once: the trip count is the task's largest top group, a lane
+        // whose group is shorter re-reads its last entry (every update below is idempotent), so there is no divergent
+        // control flow and the LDS reads of consecutive entries overlap.
+        {
             const uint64_t nrows = my_end - my_off;
             const uint32_t m = L.meta[lane];
-            bool done = true;
-            if (nrows == 0) { pack_status(ra, rb, BLU_ST_NO_HITS, 0xFFFFFFFFu); rec_kind = 1; }   // mod.rs:107-113
-            else if (nrows > MAX_TASK_SEG || !in_span) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
-            else if (m & META_SLOW) done = false;   // its step did not fit the list this round: again in the next one
-            else {
-                const uint32_t first = m & 0xFFFF, k = (m >> 16) & 0x3FF;
-                // parse errors first, in file order (find_single_query_consensus.rs:51-64), then NaN pident
-                uint32_t err = 0, err_pos = 0;
-                for (uint32_t e = 0; e < k; ++e) {
-                    const uint32_t id = L.rec[first + e].x;
-                    if (err == 0 && ((id & ROW_MASK) >= t.n_tax || (id >> BLU_ROW_BITS) == 0)) {
-                        err = (id & ROW_MASK) >= t.n_tax ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE;
-                        err_pos = L.pq[first + e];
-                    }
-                }
-                if (!PID32 && err == 0)
-                    for (uint32_t e = 0; e < k; ++e) {
-                        const double p = __hiloint2double((int)L.p1[first + e], (int)L.rec[first + e].y);
-                        if (err == 0 && p != p) { err = BLU_ST_ERR_BAD_PIDENT; err_pos = L.pq[first + e]; }
-                    }
-                if (err) { pack_status(ra, rb, err, row0 + err_pos); rec_kind = 1; }
+            const bool listed = pend && nrows != 0 && nrows <= MAX_TASK_SEG && in_span && !(m & META_SLOW) && !BLU_X_SKIP_2A;
+            const uint32_t first = listed ? (m & 0xFFFFu) : 0u, k = listed ? ((m >> 16) & 0x3FFu) : 0u;
+            const uint32_t kmax = wave_max_u32(k);
+            // parse errors in file order (find_single_query_consensus.rs:51-64), then NaN perc_identity; reference row,
+            // shortest lineage, group-max pident (find_multi_taxa_consensus.rs:39-68,142-145,182-185) and the span
+            // [lo, hi] of the group in the sorted lineage order
+            uint32_t err = 0, err_pos = 0, nan_pos = 0xFFFFFFFFu;
+            uint32_t b_len = 0, b_acc = 0, lo = 0xFFFFFFFFu, hi = 0, l_minlen = 0xFFFFFFFFu, l_row = 0, l_pos = 0;
+            int b_aln = 0;
+            PK b_pid = 0, l_maxpid = 0;   // fold(0.0, max): find_multi_taxa_consensus.rs:182-185
+#pragma unroll 2
+            for (uint32_t e = 0; e < kmax; ++e) {
+                const uint32_t idx = first + (e < k ? e : (k ? k - 1u : 0u));
+                const uint4 x = L.rec[idx];              // {row id, pident, align_len, accession rank}
+                const uint32_t xpos = L.pq[idx];
+                const uint32_t len = umin(x.x >> BLU_ROW_BITS, t.max_depth), pos = x.x & ROW_MASK;
+                const bool unmatched = pos >= t.n_tax, bad = (x.x >> BLU_ROW_BITS) == 0;
+                const bool first_err = (err == 0) & (unmatched | bad);
+                err = first_err ? (unmatched ? (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID : (uint32_t)BLU_ST_ERR_BAD_LINEAGE) : err;
+                err_pos = first_err ? xpos : err_pos;
+                PK xpid;
+                if constexpr (PID32) xpid = x.y;
                 else {
-                    // reference row, shortest lineage, group-max pident (find_multi_taxa_consensus.rs:39-68,142-145,182-185)
-                    // and the span [lo, hi] of the group in the sorted lineage order
-                    uint32_t b_len = 0, b_acc = 0, lo = 0xFFFFFFFFu, hi = 0;
-                    int b_aln = 0;
-                    minlen = 0xFFFFFFFFu;
-                    for (uint32_t e = 0; e < k; ++e) {
-                        const uint4 x = L.rec[first + e];       // {row id, pident, align_len, accession rank}
-                        const uint32_t len = umin(x.x >> BLU_ROW_BITS, t.max_depth), pos = x.x & ROW_MASK;
-                        minlen = umin(minlen, len);
-                        lo = umin(lo, pos);
-                        hi = pos > hi ? pos : hi;
-                        PK xpid;
-                        if constexpr (PID32) xpid = x.y;
-                        else xpid = __hiloint2double((int)L.p1[first + e], (int)x.y);
-                        max_pid = xpid > max_pid ? xpid : max_pid;
-                        const bool take = (e == 0) | key_better<STRAT, PK>(len, xpid, (int)x.z, x.w, b_len, r_pid, b_aln, b_acc);
-                        b_len = take ? len : b_len;
-                        r_len = b_len;
-                        r_pid = take ? xpid : r_pid;
-                        b_aln = take ? (int)x.z : b_aln;
-                        b_acc = take ? x.w : b_acc;
-                        r_row = take ? pos : r_row;
-                        r_pos = take ? (uint32_t)L.pq[first + e] : r_pos;
-                    }
+                    xpid = __hiloint2double((int)L.p1[idx], (int)x.y);
+                    nan_pos = (nan_pos == 0xFFFFFFFFu && xpid != xpid) ? xpos : nan_pos;
+                }
+                l_minlen = umin(l_minlen, len);
+                lo = umin(lo, pos);
+                hi = pos > hi ? pos : hi;
+                l_maxpid = xpid > l_maxpid ? xpid : l_maxpid;
+                const bool take = (e == 0) | key_better<STRAT, PK>(len, xpid, (int)x.z, x.w, b_len, b_pid, b_aln, b_acc);
+                b_len = take ? len : b_len;
+                b_pid = take ? xpid : b_pid;
+                b_aln = take ? (int)x.z : b_aln;
+                b_acc = take ? x.w : b_acc;
+                l_row = take ? pos : l_row;
+                l_pos = take ? xpos : l_pos;
+            }
+            if (pend) {
+                bool done = true;
+                if (nrows == 0) { pack_status(ra, rb, BLU_ST_NO_HITS, 0xFFFFFFFFu); rec_kind = 1; }   // mod.rs:107-113
+                else if (nrows > MAX_TASK_SEG || !in_span) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
+                else if (m & META_SLOW) done = false;   // its step did not fit the list this round: again in the next one
+                else if (BLU_X_SKIP_2A) { mode = 2; r_row = L.rec[m & 0xFF].x & ROW_MASK; r_len = 5; minlen = 5; }
+                else if (err) { pack_status(ra, rb, err, row0 + err_pos); rec_kind = 1; }
+                else if (!PID32 && nan_pos != 0xFFFFFFFFu) { pack_status(ra, rb, BLU_ST_ERR_BAD_PIDENT, row0 + nan_pos); rec_kind = 1; }
+                else {
+                    r_len = b_len; r_pid = b_pid; r_row = l_row; r_pos = l_pos; minlen = l_minlen; max_pid = l_maxpid;
                     mode = k == 1 ? 2u : 0u;
                     g_lo = lo; g_hi = hi;    // span of the group in sorted order: phase 2c turns it into the shared levels
                 }
+                if (done) { pend = false; L.seg[lane].y = 0u; }   // later rounds skip it
             }
-            if (done) { pend = false; L.seg[lane].y = 0u; }   // later rounds skip it
         }
+        STAMP(3)   // phase 2a
         const uint32_t pend_now = (uint32_t)__builtin_popcountll(__ballot(pend));
         if (pend_now == 0 || pend_now >= pend_before) break;      // all reduced, or a round without progress
         pend_before = pend_now;
@@ -974,7 +1060,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         if (pend) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;   // a single step larger than the whole list
 
         // ---------------- phase 2c: lane = query, cutoff tests and the record ----------------
-        if (mode != 3) {
+        if (BLU_X_SKIP_2C) { if (mode != 3) { pack_status(ra, rb, mode, r_row + minlen + r_pos + r_len + g_lo + g_hi); rec_kind = 1; } }
+        else if (mode != 3) {
             const bool single = mode == 2;
             rec_kind = 1;
             // The reference row: header, neighbour run lengths of 20 levels and the node ids in one 128-byte line (up to 20
@@ -987,13 +1074,15 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             uint4 w[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) w[k] = ref4[k];
+            STAMP_DRAIN
+            STAMP(4)   // reference rows arrive
             r_hdr = w[0].x;   // (requesting it back in phase 2a costs a second fetch: the line leaves L2 in between)
             // its length field equals the id's for a well-formed id and bounds the loops for a corrupt one
             const uint32_t len_ref = umin(r_len, r_hdr & 0xFF);
             // levels shared by the whole group (find_multi_taxa_consensus.rs:137-180): every row agrees with the reference
             // row on exactly the levels all rows of the span share, and the scan never looks past the shortest lineage
             d = minlen;
-            if (!single && g_lo < g_hi) {
+            if (!single && g_lo < g_hi && !BLU_X_SKIP_RUNLEN) {
                 const uint32_t dl = r_row - g_lo, dh = g_hi - r_row;     // lo <= reference row <= hi
                 bool by_table = dl >= 255u || dh >= 255u;               // saturated run lengths: not decidable from the row
                 if (!by_table) {
@@ -1009,6 +1098,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 }
                 if (by_table) d = umin(minlen, shared_levels(t, g_lo, g_hi));
             }
+            STAMP(5)   // shared levels from the run lengths (or the RMQ tables)
             const bool agree = single | (d >= minlen);
             if (!agree && d == 0) pack_status(ra, rb, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
             else {
@@ -1034,8 +1124,10 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 uint4 c[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) c[k] = codes4[k];
+                STAMP_DRAIN
+                STAMP(6)   // (5: run lengths / RMQ) codes arrive
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { level(4 * k, c[k].x); level(4 * k + 1, c[k].y); level(4 * k + 2, c[k].z); level(4 * k + 3, c[k].w); }
+                for (int k = 0; k < (BLU_X_SKIP_LEVELS ? 0 : 4); ++k) { level(4 * k, c[k].x); level(4 * k + 1, c[k].y); level(4 * k + 2, c[k].z); level(4 * k + 3, c[k].w); }
                 // codes word of level j again (rank codes of the reached / allowed levels): from the registers for the first
                 // 16 levels — going back to memory for them put a third dependent lookup on the task's critical path
                 const uint32_t cw[16] = {c[0].x, c[0].y, c[0].z, c[0].w, c[1].x, c[1].y, c[1].z, c[1].w,
@@ -1081,8 +1173,10 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 }
             }
         }
+        STAMP(7)   // levels, record
         // what was requested ahead for the next task has to be in the ring before that task counts its own requests
         if (ring_landed < ring_head) { wait_vmcnt(0u); ring_mark_landed(ring_head); }
+        STAMP(8)   // drain of the requests made ahead
         // ---------------- records: staged through LDS, stored as two fully coalesced 1 KiB rows ----------------
         // (a 32-byte record per lane straight to memory is 64 scattered 16-byte pieces per store instruction;
         // measured: 0.7 ms of a 2.7 ms launch.)  The list area is dead after phase 2a and is reused.
@@ -1110,7 +1204,16 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        STAMP(9)   // record staging and stores
     }
+#if defined(BLU_EXPERIMENTS) && defined(BLU_X_STAMPS)
+    if (lane < 12 && wave * 2 + 1 < h.n_queries) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v = lane == i ? (uint32_t)st_sum[i] : v;
+        reinterpret_cast<uint32_t*>(out + wave * 2)[lane] = v;
+    }
+#endif
     // The last block to finish publishes the queue length for the worklist kernel and zeroes the two counters: a run
     // leaves them as it found them — no memset between runs, and a captured graph of the two kernels can be replayed.
     __syncthreads();
