@@ -27,10 +27,12 @@ struct RankInfo {
 // Lineage rows sit in LEXICOGRAPHIC order of their node sequences (row index = "pos"; engine row ids are
 // pos | lineage length << BLU_ROW_BITS, so the streaming phase needs no taxonomy lookup).  One row:
 //   word 0             len | shape << 8   (len 0 = lineage that fails parse_taxonomy)
-//   bytes 4+2j, 5+2j   (a_j, b_j), j < 20: how many sorted rows to the left / right of this one still share its levels
-//                      0..j, saturated at 255.  The levels shared by a group spanning [lo, hi] around this row are the
-//                      levels with a_j >= pos - lo and b_j >= hi - pos (exact when both distances are < 255; wider
-//                      groups, and agreement deeper than 20 levels, use the lcp8 / rmq tables below)
+//   bytes 4+j, 24+j    0x80 | a_j and 0x80 | b_j, j < 20: how many sorted rows to the left (a) / right (b) of this one still
+//                      share its levels 0..j, saturated at 127 (levels the row does not have: 0x80).  The levels shared by a
+//                      group spanning [lo, hi] around this row are the levels with a_j >= pos - lo and b_j >= hi - pos, four
+//                      levels per 32-bit subtraction (bit 7 of a byte survives `byte - distance` exactly when the run is long
+//                      enough); exact when both distances are <= 127 — wider groups, and agreement deeper than 20 levels, use
+//                      the lcp8 / rmq tables below
 //   word 11+j          node id of level j   interned (Display(rank), identifier)
 // i.e. one 128-byte line for lineages of up to 20 levels (stride 32 words; deeper taxonomies get longer rows).  What the finalisation needs per LEVEL — cutoff, rank code, max-allowed-rank code — depends on the
 // row's shape only: codes[shape][cstride], one word per level =
@@ -56,6 +58,7 @@ struct TaxDev {
 };
 
 #define BLU_ROW_IV_LEVELS 20u    // levels whose neighbour run lengths sit in the row (words 1..10)
+#define BLU_ROW_RUN_MAX 127u     // a run length byte saturates here
 #define BLU_ROW_NODE_BASE 11u    // first node-id word of a row
 #define BLU_PACK_CUT_BITS 12u
 #define BLU_PACK_CODE_BITS 10u

@@ -228,31 +228,35 @@ __device__ __forceinline__ uint32_t exclude_mask(int s, int e) {
     const uint64_t high = ~((1ull << (8 * b)) - 1ull);
     return (uint32_t)(low | high);
 }
-// min of bytes [s, e) of the 16-byte block `blk` of lcp8 (0 <= s < e <= 16)
-__device__ __forceinline__ uint32_t block_min(const TaxDev& t, uint32_t blk, int s, int e) {
-    const uint4 w = *reinterpret_cast<const uint4*>(t.lcp8 + (uint64_t)blk * 16);
-    const uint32_t x[4] = {w.x | exclude_mask(s, e), w.y | exclude_mask(s - 4, e - 4), w.z | exclude_mask(s - 8, e - 8),
-                           w.w | exclude_mask(s - 12, e - 12)};
-    us2 acc = {0xFF, 0xFF};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t a = x[i] & 0x00FF00FFu, b = (x[i] >> 8) & 0x00FF00FFu;
-        acc = __builtin_elementwise_min(acc, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
-    }
-    return acc.x < acc.y ? acc.x : acc.y;
-}
-// min(lcp8[lo .. hi-1]) for lo < hi: number of leading levels shared by every row with lo <= pos <= hi
+// min(lcp8[lo .. hi-1]) for lo < hi: number of leading levels shared by every row with lo <= pos <= hi.
+// Branch-free: the (at most) two partial 16-entry blocks and the two sparse-table bytes are requested together and
+// combined afterwards, so a lookup is ONE memory round trip, not up to three one after the other.
 __device__ __forceinline__ uint32_t shared_levels(const TaxDev& t, uint32_t lo, uint32_t hi) {
-    const uint32_t b0 = (lo + 15) >> 4, b1 = hi >> 4;
-    if (b0 > b1) return block_min(t, lo >> 4, (int)(lo & 15), (int)(hi - ((lo >> 4) << 4)));
-    uint32_t m = 0xFF;
-    if (lo & 15) m = umin(m, block_min(t, lo >> 4, (int)(lo & 15), 16));
-    if (hi & 15) m = umin(m, block_min(t, b1, 0, (int)(hi & 15)));
-    if (b0 < b1) {
-        const uint32_t k = 31 - __builtin_clz(b1 - b0);
-        const uint8_t* lvl = t.rmq + (uint64_t)k * t.rmq_nb;
-        m = umin(m, umin(lvl[b0], lvl[b1 - (1u << k)]));
-    }
+    const uint32_t b0 = (lo + 15) >> 4, b1 = hi >> 4;          // whole blocks b0 .. b1 - 1 lie inside [lo, hi)
+    const bool one = b0 > b1;                                  // lo and hi inside one block
+    const uint32_t blk_a = lo >> 4;
+    const int s_a = (int)(lo & 15), e_a = one ? (int)(hi - (blk_a << 4)) : 16;      // head: entries [s_a, e_a) of block blk_a
+    const int e_b = one ? 0 : (int)(hi & 15);                                       // tail: entries [0, e_b) of block b1
+    const bool mid = b0 < b1;
+    const uint32_t k = mid ? 31 - __builtin_clz(b1 - b0) : 0;
+    const uint8_t* lvl = t.rmq + (uint64_t)k * t.rmq_nb;
+    const uint4 wa = *reinterpret_cast<const uint4*>(t.lcp8 + (uint64_t)blk_a * 16);
+    const uint4 wb = *reinterpret_cast<const uint4*>(t.lcp8 + (uint64_t)b1 * 16);
+    const uint32_t r0 = lvl[mid ? b0 : 0u], r1 = lvl[mid ? b1 - (1u << k) : 0u];
+    auto bmin = [](const uint4 w, const int s, const int e) {  // min of bytes [s, e) of a 16-byte block (0xFF if empty)
+        const uint32_t x[4] = {w.x | exclude_mask(s, e), w.y | exclude_mask(s - 4, e - 4), w.z | exclude_mask(s - 8, e - 8),
+                               w.w | exclude_mask(s - 12, e - 12)};
+        us2 acc = {0xFF, 0xFF};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t a = x[i] & 0x00FF00FFu, b = (x[i] >> 8) & 0x00FF00FFu;
+            acc = __builtin_elementwise_min(acc, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+        }
+        return (uint32_t)(acc.x < acc.y ? acc.x : acc.y);
+    };
+    uint32_t m = bmin(wa, s_a, (s_a != 0 || one) ? e_a : s_a);   // (a head starting at entry 0 of a whole block belongs to the middle part)
+    m = umin(m, bmin(wb, 0, e_b));
+    m = umin(m, mid ? umin(r0, r1) : 0xFFu);
     return m;
 }
 
@@ -290,6 +294,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // 4-byte column), and with nt the line is dropped before the wave's next step needs its other half — measured
 // +12 % HBM read requests (TCC_EA0_RDREQ) and +10 % time.
 #define STREAM_AUX 0
+#ifndef RING_DMA_MOD
+#define RING_DMA_MOD " sc1 nt"   // cache-policy bits of the ring's DMA requests: every bit-score is read exactly once, so the stream
+                                 // should not displace the lineage rows (re-read ~4 times per run) from L2 / Infinity Cache: -6 % on C3
+#endif
+#ifndef GATHER_AUX
+#define GATHER_AUX 2         // cache-policy bits of the gathered side records (2 = nt: read once as well)
+#endif
 #ifndef RECORD_AUX
 #define RECORD_AUX 18  // sc1 | nt
 #endif
@@ -297,13 +308,18 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // The bit-score stream of a task whose segments are all streamed goes through a per-wave LDS ring, filled by LDS-DMA
 // (buffer_load_dwordx4 ... lds: 1 KiB = 256 rows per wave instruction, no VGPR destination) well ahead of the steps that
 // read it, across task boundaries: a wave no longer pays a memory round trip per step.
+#ifndef BLU_RPL
+#define BLU_RPL 16u              // rows a lane scans in a step of a ring task (8 or 16): a step spans up to 64 BLU_RPL + 255 rows
+#endif
 #ifndef RING_ROWS
-#define RING_ROWS 2048u          // power of two, multiple of 256; a step spans up to 1024 + 255 rows
+#define RING_ROWS (BLU_RPL * 128u)   // power of two, multiple of 256: the chunks of one step and what is requested ahead
 #endif
 #define RING_PAD 32u              // >= rows one lane scans in a step
 #define RING_CHUNKS (RING_ROWS / 256u)
 #define RING_MASK (RING_ROWS - 1u)
-static_assert((RING_ROWS & RING_MASK) == 0 && RING_ROWS >= 2048u, "ring size");
+static_assert((RING_ROWS & RING_MASK) == 0 && RING_ROWS >= BLU_RPL * 64u + 512u, "ring size");
+static_assert(BLU_RPL == 8u || BLU_RPL == 16u, "rows per lane");
+#define DESC_SUB_BITS (BLU_RPL == 16u ? 3u : 4u)   // lane descriptor word: top-row mask (BLU_RPL bits) | first row (13 bits) | position / BLU_RPL
 static_assert(LIST_CAP >= 128 && LIST_CAP_F64 >= 128, "the list area also stages the 64 records of a task");
 
 template <bool F64>
@@ -400,7 +416,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         const uint32_t dst = ring_lds + (c & (RING_CHUNKS - 1u)) * 1024u;
         const uint32_t voff = (c - c0) * 1024u + (uint32_t)lane * 16u;
         uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen" RING_DMA_MOD " lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs) : "memory");
     };
 
@@ -410,7 +426,13 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         o = 0; e = 0;
         if (tk < n_tasks) {
             const uint64_t q = tk * WAVE + (uint32_t)lane;
-            if (q < h.n_queries) { o = h.seg_off[q]; e = h.seg_off[q + 1]; }
+            if (q < h.n_queries) {
+#ifdef BLU_SEG_NT
+                o = __builtin_nontemporal_load(h.seg_off + q); e = __builtin_nontemporal_load(h.seg_off + q + 1);
+#else
+                o = h.seg_off[q]; e = h.seg_off[q + 1];
+#endif
+            }
         }
     };
     uint64_t nx_off, nx_end;
@@ -804,6 +826,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 if (LPQ >= 2) M = imax(M, dpp<0xB1>(M));
                 if (LPQ >= 4) M = imax(M, dpp<0x4E>(M));
                 if (LPQ >= 8) M = imax(M, dpp<0x141>(M));             // row_half_mirror
+                if (LPQ >= 16) M = imax(M, dpp<0x140>(M));            // row_mirror
                 if (BLU_X_SCAN_MIN) { if (sub == 0) L.meta[qi] = (uint32_t)M & 0xFFu; continue; }
                 uint32_t mask = 0;                                    // bit RPL - 1 - i = row i ties on the query's top score
 #pragma unroll
@@ -824,6 +847,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 if (LPQ >= 2) gk += (uint32_t)dpp<0xB1>((int)gk);
                 if (LPQ >= 4) gk += (uint32_t)dpp<0x4E>((int)gk);
                 if (LPQ >= 8) gk += (uint32_t)dpp<0x141>((int)gk);
+                if (LPQ >= 16) gk += (uint32_t)dpp<0x140>((int)gk);
                 uint32_t idx = rbase + incl - c;                      // list slot of this lane's first top row (file order)
                 if (sub == 0) L.meta[qi] = fits ? (idx | (gk << 16)) : META_SLOW;
                 if (!fits) {                                          // the list is full: the rest of the task in the next round,
@@ -833,43 +857,70 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     break;
                 }
                 fill = p3 + k3;
-                STAMP(1)
-                uint32_t m = mask;
-                while (__ballot(m != 0u)) {
-                    if (m) {
-                        const uint32_t hb = 31u - (uint32_t)__builtin_clz(m), i = RPL - 1u - hb;
-                        L.rec[idx].x = row0 + i;                      // the row, relative to the task's first row: gather_list turns it into the side record
-                        L.pq[idx] = (uint16_t)(sub + i);
-                        ++idx;
-                        m &= ~(1u << hb);
-                    }
-                }
-                STAMP(11)   // (writing the list)
+                // a lane with top rows leaves ONE word in the list, at the slot of its first top row: which of its rows are top
+                // rows (RPL bits), its first row relative to the task (13 bits: a ring task has at most 64 x 128 rows) and its
+                // position in the segment / RPL; the slots in between stay 0 and gather_list works the entries out
+                static_assert(RPL == BLU_RPL && SHORT_SEG <= 128u, "descriptor word of a lane");
+                if (c) L.rec[idx].x = (mask << (32u - RPL)) | (row0 << DESC_SUB_BITS) | (sub / RPL);
             }
         };
-        // the 16 other bytes of the list's rows: one entry per lane, every load of the round in flight before the first is used
+        // The list entries of a ring round: lane e of a 64-entry chunk finds the lane descriptor its entry belongs to (the last
+        // non-zero word at or before slot e: a max-scan over the chunk, carried from chunk to chunk), picks the row out of
+        // the descriptor's bit mask, and requests the 16 other bytes of that row — every load of the round in flight before
+        // the first is used.  `between` runs while they travel.
         auto gather_list = [&](auto&& between) {
             constexpr int NG = (CAP + WAVE - 1) / WAVE;
             u32x4 g[NG];
-            uint32_t ghi[NG];
+            uint32_t ghi[NG], gpos[NG];
+            uint32_t carry = 0;                                        // slot of the last descriptor seen so far (slot 0 always holds one)
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
+                g[u] = u32x4{0u, 0u, 0u, 0u}; ghi[u] = 0u; gpos[u] = 0u;
+                if ((uint32_t)u * WAVE >= fill) continue;             // (wave-uniform)
                 const uint32_t idx = (uint32_t)u * WAVE + (uint32_t)lane;
                 const bool valid = idx < fill;
-                const uint32_t row = valid ? L.rec[idx < CAP ? idx : 0u].x : 0u;
-                g[u] = u32x4{0u, 0u, 0u, 0u}; ghi[u] = 0u;
-                if ((uint32_t)u * WAVE >= fill) continue;             // (wave-uniform)
-                if (PACKED) g[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, valid ? row * 16u : 0xFFFFFFC0u, 0, STREAM_AUX);
+                const uint32_t d0 = L.rec[idx < CAP ? idx : 0u].x;
+                int s = (valid && d0 != 0u) ? (int)idx : 0;           // inclusive max-scan: slot of the descriptor that owns entry idx
+                s = imax(s, dpp<0x111>(s));
+                s = imax(s, dpp<0x112>(s));
+                s = imax(s, dpp<0x114>(s));
+                s = imax(s, dpp<0x118>(s));
+                s = imax(s, __builtin_amdgcn_update_dpp(0, s, 0x142, 0xA, 0xF, false));   // row_bcast:15 into rows 1 and 3
+                s = imax(s, __builtin_amdgcn_update_dpp(0, s, 0x143, 0xC, 0xF, false));   // row_bcast:31 into rows 2 and 3
+                s = imax(s, (int)carry);
+                carry = (uint32_t)rl(s, 63);
+                const uint32_t d = L.rec[s].x;
+                // the (idx - s + 1)-th set bit of the mask, counted from its top bit (= the lane's row 0)
+                uint32_t r = idx - (uint32_t)s, x = d >> (32u - BLU_RPL), i = 0;
+                if (BLU_RPL == 16u) {
+                    const uint32_t h = x >> 8, ch = (uint32_t)__builtin_popcount(h);
+                    const bool low = r >= ch;
+                    r -= low ? ch : 0u; x = low ? (x & 0xFFu) : h; i += low ? 8u : 0u;
+                }
+                {
+                    const uint32_t h = x >> 4, ch = (uint32_t)__builtin_popcount(h);
+                    const bool low = r >= ch;
+                    r -= low ? ch : 0u; x = low ? (x & 0xFu) : h; i += low ? 4u : 0u;
+                }
+                {
+                    const uint32_t h = x >> 2, ch = (uint32_t)__builtin_popcount(h);
+                    const bool low = r >= ch;
+                    r -= low ? ch : 0u; x = low ? (x & 0x3u) : h; i += low ? 2u : 0u;
+                }
+                i += (r >= (x >> 1)) ? 1u : 0u;
+                const uint32_t row = ((d >> DESC_SUB_BITS) & 0x1FFFu) + i;
+                gpos[u] = (d & ((1u << DESC_SUB_BITS) - 1u)) * BLU_RPL + i;
+                if (PACKED) g[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, valid ? row * 16u : 0xFFFFFFC0u, 0, GATHER_AUX);
                 else {
                     const uint32_t o4 = valid ? row * 4u : 0xFFFFFFF0u;
-                    g[u].x = __builtin_amdgcn_raw_buffer_load_b32(rs_tax, o4, 0, STREAM_AUX);
-                    if (PID32) g[u].y = __builtin_amdgcn_raw_buffer_load_b32(rs_pid, o4, 0, STREAM_AUX);
+                    g[u].x = __builtin_amdgcn_raw_buffer_load_b32(rs_tax, o4, 0, GATHER_AUX);
+                    if (PID32) g[u].y = __builtin_amdgcn_raw_buffer_load_b32(rs_pid, o4, 0, GATHER_AUX);
                     else {
-                        const u32x2 p = __builtin_amdgcn_raw_buffer_load_b64(rs_pid, valid ? row * 8u : 0xFFFFFFE0u, 0, STREAM_AUX);
+                        const u32x2 p = __builtin_amdgcn_raw_buffer_load_b64(rs_pid, valid ? row * 8u : 0xFFFFFFE0u, 0, GATHER_AUX);
                         g[u].y = p.x; ghi[u] = p.y;
                     }
-                    g[u].z = __builtin_amdgcn_raw_buffer_load_b32(rs_aln, o4, 0, STREAM_AUX);
-                    g[u].w = __builtin_amdgcn_raw_buffer_load_b32(rs_acc, o4, 0, STREAM_AUX);
+                    g[u].z = __builtin_amdgcn_raw_buffer_load_b32(rs_aln, o4, 0, GATHER_AUX);
+                    g[u].w = __builtin_amdgcn_raw_buffer_load_b32(rs_acc, o4, 0, GATHER_AUX);
                 }
             }
             between();
@@ -878,6 +929,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 const uint32_t idx = (uint32_t)u * WAVE + (uint32_t)lane;
                 if (idx < fill) {
                     L.rec[idx] = make_uint4(g[u].x, g[u].y, g[u].z, g[u].w);
+                    L.pq[idx] = (uint16_t)gpos[u];
                     if (!PID32) L.p1[idx] = ghi[u];
                 }
             }
@@ -934,7 +986,15 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
 #endif
             const uint32_t longest = wave_max_u32(rows > short_seg ? 0u : rows);   // longest streamed segment of the task
             ring_round = contiguous && longest != 0u && __ballot(rows > short_seg) == 0ull;
-            if (ring_round) phase1_scan(std::integral_constant<uint32_t, 16>(), longest <= 16u ? 1u : (longest <= 32u ? 2u : (longest <= 64u ? 4u : 8u)));
+            if (ring_round) {
+#pragma unroll
+                for (uint32_t u = 0; u * WAVE < CAP; ++u) { const uint32_t i = u * WAVE + (uint32_t)lane; if (i < CAP) L.rec[i].x = 0u; }   // (no entry starts here)
+            }
+            if (ring_round) {
+                uint32_t lpq = 1;
+                while (lpq * BLU_RPL < longest) lpq *= 2;                 // 1 .. 128 / BLU_RPL lanes per query
+                phase1_scan(std::integral_constant<uint32_t, BLU_RPL>(), lpq);
+            }
             else if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>(), false);   // the C3 shape, specialised
             else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u), longest >= (PACKED ? 9u : 25u));   // two-stage steps: measured break-even (packed records: 10 hits -2.5 %, 20 hits -17 %; columns: 20 hits +3 %, 30 hits -6 %)
             // queries phase 1 did not get to (the list filled up): marked for the next round, long ones included
@@ -1074,29 +1134,36 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             uint4 w[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) w[k] = ref4[k];
+            // Levels shared by the whole group (find_multi_taxa_consensus.rs:137-180): every row agrees with the reference row on
+            // exactly the levels all rows of the span [lo, hi] share, and the scan never looks past the shortest lineage.
+            // Seen from the reference row r that is the number of levels whose run reaches dl = r - lo rows to the left and
+            // dh = hi - r rows to the right: 20 byte compares on the row that is read anyway, exact below 127 rows either
+            // side.  A wider group asks the range-minimum tables, and asks them NOW: the span is known since phase 2a, so
+            // those lookups travel together with the reference row instead of after it.
+            const bool spread = !single && g_lo < g_hi && !BLU_X_SKIP_RUNLEN;
+            const uint32_t dl = r_row - g_lo, dh = g_hi - r_row;     // lo <= reference row <= hi
+            const bool wide = spread && (dl > BLU_ROW_RUN_MAX || dh > BLU_ROW_RUN_MAX);   // saturated run lengths: not decidable from the row
+            uint32_t d_tab = 0;
+            if (wide) d_tab = shared_levels(t, g_lo, g_hi);
             STAMP_DRAIN
             STAMP(4)   // reference rows arrive
             r_hdr = w[0].x;   // (requesting it back in phase 2a costs a second fetch: the line leaves L2 in between)
             // its length field equals the id's for a well-formed id and bounds the loops for a corrupt one
             const uint32_t len_ref = umin(r_len, r_hdr & 0xFF);
-            // levels shared by the whole group (find_multi_taxa_consensus.rs:137-180): every row agrees with the reference
-            // row on exactly the levels all rows of the span share, and the scan never looks past the shortest lineage
             d = minlen;
-            if (!single && g_lo < g_hi && !BLU_X_SKIP_RUNLEN) {
-                const uint32_t dl = r_row - g_lo, dh = g_hi - r_row;     // lo <= reference row <= hi
-                bool by_table = dl >= 255u || dh >= 255u;               // saturated run lengths: not decidable from the row
-                if (!by_table) {
-                    const uint32_t iw[10] = {w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w, w[2].x, w[2].y, w[2].z};
-                    uint32_t cnt = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < BLU_ROW_IV_LEVELS; ++j) {
-                        const uint32_t pair = (iw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                        cnt += (uint32_t)((j < len_ref) & ((pair & 0xFFu) >= dl) & ((pair >> 8) >= dh));   // monotone in j
-                    }
-                    if (cnt >= BLU_ROW_IV_LEVELS && minlen > BLU_ROW_IV_LEVELS) by_table = true;   // agreement deeper than the row's run lengths
-                    else d = umin(minlen, cnt);
-                }
-                if (by_table) d = umin(minlen, shared_levels(t, g_lo, g_hi));
+            if (wide) d = umin(minlen, d_tab);
+            else if (spread) {
+                // bytes 0x80 | min(run, 127), levels 0 .. 19: left runs in words 1 .. 5, right runs in words 6 .. 10 (levels the row
+                // does not have hold 0x80).  byte - dl keeps bit 7 exactly when run >= dl, and no byte borrows from its neighbour.
+                const uint32_t ca = dl * 0x01010101u, cb = dh * 0x01010101u, H = 0x80808080u;
+                uint32_t cnt = 0;
+                cnt += (uint32_t)__builtin_popcount((w[0].y - ca) & (w[1].z - cb) & H);
+                cnt += (uint32_t)__builtin_popcount((w[0].z - ca) & (w[1].w - cb) & H);
+                cnt += (uint32_t)__builtin_popcount((w[0].w - ca) & (w[2].x - cb) & H);
+                cnt += (uint32_t)__builtin_popcount((w[1].x - ca) & (w[2].y - cb) & H);
+                cnt += (uint32_t)__builtin_popcount((w[1].y - ca) & (w[2].z - cb) & H);
+                if (cnt >= BLU_ROW_IV_LEVELS && minlen > BLU_ROW_IV_LEVELS) d = umin(minlen, shared_levels(t, g_lo, g_hi));   // agreement deeper than the row's run lengths
+                else d = umin(minlen, cnt);
             }
             STAMP(5)   // shared levels from the run lengths (or the RMQ tables)
             const bool agree = single | (d >= minlen);

@@ -320,11 +320,11 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         while (c < m && ra[1 + c] == rb[1 + c]) ++c;
         lcp8[i] = (uint8_t)c;
     }
-    // Device rows: word 0 = len | shape << 8; words 1..10 = for each of the first 20 levels a byte pair (a_j, b_j) = how
-    // many sorted rows to the left / right of this row still share its levels 0..j, saturated at 255; words 11.. = the
-    // node ids.  With them the levels shared by a group spanning [lo, hi] around row r are the levels with
-    // a_j >= r - lo and b_j >= hi - r — exact whenever both distances are below 255, which is the common case (the group
-    // sits inside one genus or family); wider groups, and agreement deeper than 20 levels, use the range-minimum
+    // Device rows: word 0 = len | shape << 8; words 1..5 / 6..10 = for each of the first 20 levels a byte 0x80 | a_j / 0x80 | b_j,
+    // a_j / b_j = how many sorted rows to the left / right of this row still share its levels 0..j, saturated at 127;
+    // words 11.. = the node ids.  With them the levels shared by a group spanning [lo, hi] around row r are the levels
+    // with a_j >= r - lo and b_j >= hi - r — exact whenever both distances are at most 127, which is the common case (the
+    // group sits inside one genus or family); wider groups, and agreement deeper than 20 levels, use the range-minimum
     // tables.  One 128-byte line holds it all for lineages of up to 20 levels.
     const uint32_t D = std::max<uint32_t>(tax->max_depth, 1);
     const uint32_t node_base = BLU_ROW_NODE_BASE;
@@ -339,12 +339,13 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
             uint32_t* dst = &dev_rows[(size_t)r * dstride];
             const uint32_t len = src[0] & 0xFF;
             dst[0] = src[0];
+            memset(dst + 1, 0x80, 2 * BLU_ROW_IV_LEVELS);               // run length 0 at every level until the passes below say otherwise
             for (uint32_t j = 0; j < len; ++j) dst[node_base + j] = src[1 + j];
             const uint32_t shared = r > 0 ? lcp8[r - 1] : 0;          // levels shared with the previous row
             uint8_t* ab = reinterpret_cast<uint8_t*>(dst + 1);
             for (uint32_t j = 0; j < len; ++j) {
                 if (j >= shared) run[j] = (uint32_t)r;                   // a new run starts here at level j
-                if (j < BLU_ROW_IV_LEVELS) ab[2 * j] = (uint8_t)std::min<uint64_t>(r - run[j], 255);
+                if (j < BLU_ROW_IV_LEVELS) ab[j] = (uint8_t)(0x80u | std::min<uint64_t>(r - run[j], BLU_ROW_RUN_MAX));
             }
             for (uint32_t j = len; j < D; ++j) run[j] = (uint32_t)r + 1; // levels this row does not have break the runs
         }
@@ -355,7 +356,7 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
             uint8_t* ab = reinterpret_cast<uint8_t*>(dst + 1);
             for (uint32_t j = 0; j < len; ++j) {
                 if (j >= shared) run[j] = (uint32_t)r;
-                if (j < BLU_ROW_IV_LEVELS) ab[2 * j + 1] = (uint8_t)std::min<uint64_t>(run[j] - r, 255);
+                if (j < BLU_ROW_IV_LEVELS) ab[BLU_ROW_IV_LEVELS + j] = (uint8_t)(0x80u | std::min<uint64_t>(run[j] - r, BLU_ROW_RUN_MAX));
             }
             for (uint32_t j = len; j < D; ++j) run[j] = (uint32_t)r;   // (never read before being reset: j >= shared for the next row)
         }
