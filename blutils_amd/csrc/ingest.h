@@ -30,7 +30,7 @@ struct NoInitAlloc : std::allocator<T> {
 template <class T> using Column = std::vector<T, NoInitAlloc<T>>;
 
 // taxid -> row of the taxonomy table; open addressing, 16-byte entries (one cache line touched per lookup: the join
-// runs once per hit row).  First insertion wins for a duplicated taxid.
+// runs once per hit row).  A duplicated taxid is refused by the loaders (pipeline.cpp).
 struct TaxidMap {
     struct E { int64_t key; uint32_t val, used; };
     std::vector<E> tab = std::vector<E>(1024, E{0, 0, 0});
@@ -48,13 +48,15 @@ struct TaxidMap {
         tab[i] = E{k, v, 1};
     }
     void reserve(size_t want) { size_t cap = tab.size(); while (cap < want * 2) cap *= 2; if (cap != tab.size()) rehash(cap); }
-    void emplace(int64_t k, uint32_t v) {
+    // false: the key was there already (the table is left as it was)
+    bool emplace(int64_t k, uint32_t v) {
         if ((n + 1) * 2 > tab.size()) rehash(tab.size() * 2);
         const size_t m = tab.size() - 1;
         size_t i = mixk(k) & m;
-        while (tab[i].used) { if (tab[i].key == k) return; i = (i + 1) & m; }
+        while (tab[i].used) { if (tab[i].key == k) return false; i = (i + 1) & m; }
         tab[i] = E{k, v, 1};
         ++n;
+        return true;
     }
     uint32_t find_or(int64_t k, uint32_t missing) const {
         const size_t m = tab.size() - 1;

@@ -178,9 +178,11 @@ __global__ __launch_bounds__(256) void parse_rows(const unsigned char* __restric
         const uint64_t len = fend - fstart;
         if (col == 0) { o.qh[i] = hash_finish(h, (uint32_t)len); o.qpos[i] = fstart | (len << 44); if (len >= (1u << 20)) fb |= FB_COLUMNS; }
         else if (col == 1) { o.ah[i] = hash_finish(h, (uint32_t)len); o.apos[i] = fstart | (len << 44); if (len >= (1u << 20)) fb |= FB_COLUMNS; }
-        else if (col == 2) { if (!num.value(&v_tax)) fb |= FB_NUMBER; }
+        // (subject_taxid and align_length are Int64 columns, mod.rs:226-244: a fraction or an exponent is left to the CPU
+        // parser, which refuses the file as the reference would)
+        else if (col == 2) { if (!num.value(&v_tax) || num.seen_dot || num.seen_exp) fb |= FB_NUMBER; }
         else if (col == 3) { if (!num.value(&v_pid)) fb |= FB_NUMBER; }
-        else if (col == 4) { if (!num.value(&v_aln)) fb |= FB_NUMBER; }
+        else if (col == 4) { if (!num.value(&v_aln) || num.seen_dot || num.seen_exp) fb |= FB_NUMBER; }
         else if (col == 12) { if (!num.value(&v_bs)) fb |= FB_NUMBER; }
         ++col;
         fstart = fend + 1;

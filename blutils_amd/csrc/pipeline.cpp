@@ -109,10 +109,18 @@ struct Json {
     }
     bool number(double* out) {
         ws();
+        // the token is copied first: the mapped file is not NUL-terminated, and a number may be its last bytes
+        char tok[64];
+        size_t n = 0;
+        while (p + n < end && n < sizeof tok - 1 && (((unsigned)(p[n] - '0') < 10u) || p[n] == '-' || p[n] == '+' || p[n] == '.' || p[n] == 'e' || p[n] == 'E')) {
+            tok[n] = p[n];
+            ++n;
+        }
+        tok[n] = 0;
         char* e = nullptr;
-        double v = strtod(p, &e);
-        if (e == p) { ok = false; return false; }
-        p = e;
+        double v = strtod(tok, &e);
+        if (e == tok) { ok = false; return false; }
+        p += e - tok;
         if (out) *out = v;
         return true;
     }
@@ -153,6 +161,7 @@ struct Db {
     std::unordered_map<std::string, uint16_t> rank_ids;
     std::unordered_map<std::string, uint32_t> node_ids;   // key: Display(rank) + '\x1f' + identifier
     TaxidMap row_of;
+    int64_t dup_taxid = INT64_MIN;           // first taxid seen twice while loading (refused: see add_lineage)
 };
 
 std::string canonical_display(const std::string& raw) {
@@ -196,7 +205,10 @@ void add_lineage(Db& db, int64_t taxid, const std::string& lineage) {
     }
     if (bad) { db.lin_node.resize(first); db.lin_rank.resize(first); }
     db.bad.push_back(bad ? 1 : 0);
-    db.row_of.emplace(taxid, (uint32_t)db.taxid.size());   // first row wins for a duplicated taxid
+    // The reference joins with polars (mod.rs:72-76): a taxid listed twice would DUPLICATE every hit row of that subject
+    // (and so change top groups and `occurrences`).  blutils databases list a taxid once; one that does not is refused
+    // rather than joined differently from the reference.
+    if (!db.row_of.emplace(taxid, (uint32_t)db.taxid.size()) && db.dup_taxid == INT64_MIN) db.dup_taxid = taxid;
     db.taxid.push_back(taxid);
     db.lin_off.push_back(db.lin_node.size());
 }
@@ -272,7 +284,8 @@ int load_db_cache(const MappedFile& f, bool use_taxid, Db& db) {
     db.node_ident.resize(h.n_nodes);
     for (uint64_t i = 0; i < h.n_nodes; ++i) db.node_ident[i].assign(nbytes + noff[i], noff[i + 1] - noff[i]);
     db.row_of.reserve(h.n_tax);
-    for (uint64_t i = 0; i < h.n_tax; ++i) db.row_of.emplace(db.taxid[i], (uint32_t)i);   // first row wins for a duplicated taxid
+    for (uint64_t i = 0; i < h.n_tax; ++i)
+        if (!db.row_of.emplace(db.taxid[i], (uint32_t)i)) { set_error("taxonomy cache: taxid %lld is listed more than once (the reference's left join would duplicate its hit rows)", (long long)db.taxid[i]); return BLU_ERR_PARSE; }
     return BLU_OK;
 }
 
@@ -347,6 +360,7 @@ int load_db(const char* path, bool use_taxid, Db& db) {
         } while (j.ok && j.eat(','));
     }
     if (!j.ok || !found) { set_error("Unexpected error detected on parse `taxonomies` as json (offset %zu)", (size_t)(j.p - f.data)); return BLU_ERR_PARSE; }
+    if (db.dup_taxid != INT64_MIN) { set_error("taxonomies file: taxid %lld is listed more than once (the reference's left join would duplicate its hit rows)", (long long)db.dup_taxid); return BLU_ERR_PARSE; }
     return BLU_OK;
 }
 
@@ -368,7 +382,7 @@ std::string strip_quotes(std::string_view v) {   // mod.rs:169-172 `.replace("\"
 bool parse_f64(std::string_view v, double* out) {
     const char* b = v.data();
     const char* e = b + v.size();
-    while (b < e && (*b == ' ')) ++b;
+    if (b == e) return false;
     {
         static const double p10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
         const char* p = b;
@@ -393,10 +407,29 @@ bool parse_f64(std::string_view v, double* out) {
     }
     auto r = std::from_chars(b, e, *out);
     if (r.ec == std::errc() && r.ptr == e) return true;
+    if ((unsigned char)*b <= ' ') return false;         // (strtod would skip leading blanks; a typed CSV column does not)
     std::string tmp(v);
     char* endp = nullptr;
     *out = strtod(tmp.c_str(), &endp);
-    return endp != tmp.c_str();
+    return endp == tmp.c_str() + tmp.size();            // the whole field, or it is not a number ("12abc")
+}
+
+// subject_taxid and align_length are Int64 columns of the reference's schema (mod.rs:226-244): [+-]digits and nothing
+// else — no fraction, exponent or blanks ("12.7" fails there, so it fails here)
+bool parse_i64(std::string_view v, int64_t* out) {
+    const char* p = v.data();
+    const char* e = p + v.size();
+    if (p == e) return false;
+    const bool neg = *p == '-';
+    if (*p == '-' || *p == '+') ++p;
+    if (p == e || e - p > 18) return false;
+    int64_t x = 0;
+    for (; p < e; ++p) {
+        if ((unsigned)(*p - '0') >= 10u) return false;
+        x = x * 10 + (*p - '0');
+    }
+    *out = neg ? -x : x;
+    return true;
 }
 
 struct RawRow { uint32_t lq, la, tax; int32_t bs, aln; double pid; };   // lq / la: the chunk's own query / accession ids
@@ -507,14 +540,15 @@ void parse_chunk(Chunk& c, const Db& db, const char* path) {
                          (unsigned long long)line_no, (unsigned long long)c.first_line, path, nc);
                 c.rc = BLU_ERR_PARSE; c.err = msg; return;
             }
-            double taxid_f, pid, aln, bs;
-            if (!parse_f64(col[2], &taxid_f) || !parse_f64(col[3], &pid) || !parse_f64(col[4], &aln) || !parse_f64(col[12], &bs)) {
+            double pid, bs;
+            int64_t taxid_i, aln;
+            if (!parse_i64(col[2], &taxid_i) || !parse_f64(col[3], &pid) || !parse_i64(col[4], &aln) || !parse_f64(col[12], &bs)) {
                 snprintf(msg, sizeof msg, "line %llu(+%llu) of %s: numeric column does not parse", (unsigned long long)line_no,
                          (unsigned long long)c.first_line, path);
                 c.rc = BLU_ERR_PARSE; c.err = msg; return;
             }
             const double bs_t = std::trunc(bs);               // mod.rs:184 AnyValue::Float64 -> try_extract::<i64>
-            if (!(bs_t >= -2147483648.0 && bs_t <= 2147483647.0) || !(aln >= -2147483648.0 && aln <= 2147483647.0)) {
+            if (!(bs_t >= -2147483648.0 && bs_t <= 2147483647.0) || aln < INT32_MIN || aln > INT32_MAX) {
                 snprintf(msg, sizeof msg, "line %llu(+%llu) of %s: bit_score / align_length outside the 32-bit range of the engine columns",
                          (unsigned long long)line_no, (unsigned long long)c.first_line, path);
                 c.rc = BLU_ERR_PARSE; c.err = msg; return;
@@ -531,7 +565,7 @@ void parse_chunk(Chunk& c, const Db& db, const char* path) {
             have_last = true;
             ++c.q_count[last_q];
             r.lq = last_q; r.la = last_a;
-            r.tax = db.row_of.find_or((int64_t)taxid_f, BLU_UNMATCHED_TAXID);    // left join (mod.rs:72-76)
+            r.tax = db.row_of.find_or(taxid_i, BLU_UNMATCHED_TAXID);    // left join (mod.rs:72-76)
             if (r.tax == BLU_UNMATCHED_TAXID) ++c.unmatched;
             r.bs = (int32_t)bs_t; r.aln = (int32_t)aln; r.pid = pid;
             c.rows.push_back(r);

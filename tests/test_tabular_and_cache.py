@@ -90,14 +90,15 @@ def test_build_tabular_cli_and_config_run_id(tmp_path, capsys):
         cli.main(["blastn", "build-tabular", str(tmp_path / "bad.json")])
 
 
-def _write_db(tmp_path, n=3000):
+def _write_db(tmp_path, n=3000, duplicate=False):
     tax = synth.make_taxonomy(n, 11)
     lt, ln = tax.lineage_strings(text=True), tax.lineage_strings(text=False)
     lt[5] = "d__bacteria;broken"                                   # a lineage that fails parse_taxonomy
     db = {"blutilsVersion": "8.3.1", "sourceDatabase": "synthetic", "taxonomies": [
         {"taxid": int(tax.taxid[t]), "rank": "species", "numericLineage": ln[t], "textLineage": lt[t], "accessions": []}
         for t in range(n)]}
-    db["taxonomies"].append(dict(db["taxonomies"][7], textLineage="d__other"))   # duplicated taxid: first row wins
+    if duplicate:
+        db["taxonomies"].append(dict(db["taxonomies"][7], textLineage="d__other"))
     tj = tmp_path / "tax.blutils.json"
     tj.write_text(json.dumps(db))
     rng = np.random.default_rng(3)
@@ -113,6 +114,26 @@ def _write_db(tmp_path, n=3000):
     return str(bt), str(tj)
 
 
+def test_a_taxid_listed_twice_is_refused(tmp_path):
+    """The reference joins hits and taxonomies with polars (mod.rs:72-76): a taxid listed twice would duplicate every hit
+    row of that subject.  Neither loader joins differently from that in silence: both refuse the file, and so does the
+    strict number parsing of the Int64 columns ("12.7" as align_length, "12abc" as a score)."""
+    bt, tj = _write_db(tmp_path, duplicate=True)
+    with pytest.raises(N.BluError, match="listed more than once"):
+        pipeline.ingest_only(bt, tj, False)
+    with pytest.raises(N.BluError, match="listed more than once"):
+        cli.main(["cache-db", tj, str(tmp_path / "dup.blucache")])
+    bt, tj = _write_db(tmp_path)
+    good = open(bt).read().splitlines()
+    cols = good[3].split("\t")
+    for col, value in ((4, cols[4] + ".7"), (2, cols[2] + "e0"), (12, cols[12] + "abc"), (3, " " + cols[3])):
+        c = list(cols)
+        c[col] = value
+        (tmp_path / "bad.tsv").write_text("\n".join(good[:3] + ["\t".join(c)] + good[4:]) + "\n")
+        with pytest.raises(N.BluError, match="does not parse"):
+            pipeline.ingest_only(str(tmp_path / "bad.tsv"), tj, False)
+
+
 @pytest.mark.parametrize("use_taxid", [False, True])
 def test_db_cache_gives_the_same_ingest(tmp_path, use_taxid):
     bt, tj = _write_db(tmp_path)
@@ -123,7 +144,7 @@ def test_db_cache_gives_the_same_ingest(tmp_path, use_taxid):
     assert ck_json == ck_bin
     for k in ("n_hits", "n_queries", "n_taxids", "n_unmatched_rows"):
         assert st_json[k] == st_bin[k]
-    assert st_json["n_taxids"] == 3001 and st_json["n_unmatched_rows"] > 0
+    assert st_json["n_taxids"] == 3000 and st_json["n_unmatched_rows"] > 0
     # wrong flavour, truncation and bit rot are refused
     with pytest.raises(N.BluError) as e:
         pipeline.ingest_only(bt, cache, not use_taxid)
