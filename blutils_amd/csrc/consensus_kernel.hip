@@ -72,6 +72,7 @@ namespace blu {
 // In-kernel stamps (experiment builds only: -DBLU_EXPERIMENTS -DBLU_X_STAMPS): s_memtime at the phase boundaries of the
 // stream kernel, summed per wave and written over the first records of `out` when the wave is done (scripts/stamps.py).
 #if defined(BLU_EXPERIMENTS) && defined(BLU_X_STAMPS)
+__device__ uint32_t g_stamps[8192 * 16];   // [wave][16]: cycles per phase, summed over the wave's tasks (read by blu_debug_stamps)
 #define STAMP_DECL uint64_t st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t st_prev = __builtin_amdgcn_s_memtime();
 #define STAMP(i) { const uint64_t st_now = __builtin_amdgcn_s_memtime(); st_sum[i] += st_now - st_prev; st_prev = st_now; }
 #define STAMP_DRAIN asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -849,13 +850,23 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 if (LPQ >= 8) gk += (uint32_t)dpp<0x141>((int)gk);
                 if (LPQ >= 16) gk += (uint32_t)dpp<0x140>((int)gk);
                 uint32_t idx = rbase + incl - c;                      // list slot of this lane's first top row (file order)
-                if (sub == 0) L.meta[qi] = fits ? (idx | (gk << 16)) : META_SLOW;
-                if (!fits) {                                          // the list is full: the rest of the task in the next round,
-                    stop_q = qn;                                      // which reads this step's rows again — their chunks were given
-                    wait_vmcnt(0u);                                   // back above, so the ring starts over at the step's first row
-                    ring_head = ring_landed = ring_tail = (uint32_t)((vbase + r_lo) >> 8);
+                if (!fits) {
+                    // The list is full.  The queries of this step whose top rows still fit are taken (slots go in query
+                    // order, so they are the ones before the first lane that runs past the end); the rest of the task
+                    // comes in the next round, which reads its rows again — their chunks were given back above, so the ring
+                    // starts over at the first row of the first query left.
+                    const uint32_t lane_o = (uint32_t)__builtin_ctzll(__ballot(idx + c > CAP));
+                    const uint32_t qo = qb + lane_o / LPQ;            // first query that does not fit
+                    const bool taken = qi < qo;
+                    if (sub == 0) L.meta[qi] = taken ? (idx | (gk << 16)) : META_SLOW;
+                    if (taken && c) L.rec[idx].x = (mask << (32u - RPL)) | (row0 << DESC_SUB_BITS) | (sub / RPL);
+                    fill = (uint32_t)rl((int)idx, (int)((qo - qb) * LPQ));   // where the first query left would have started
+                    stop_q = qo;
+                    wait_vmcnt(0u);
+                    ring_head = ring_landed = ring_tail = (uint32_t)((vbase + (uint32_t)rl((int)seg_x, (int)qo)) >> 8);
                     break;
                 }
+                if (sub == 0) L.meta[qi] = idx | (gk << 16);
                 fill = p3 + k3;
                 // a lane with top rows leaves ONE word in the list, at the slot of its first top row: which of its rows are top
                 // rows (RPL bits), its first row relative to the task (13 bits: a ring task has at most 64 x 128 rows) and its
@@ -1274,11 +1285,11 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         STAMP(9)   // record staging and stores
     }
 #if defined(BLU_EXPERIMENTS) && defined(BLU_X_STAMPS)
-    if (lane < 12 && wave * 2 + 1 < h.n_queries) {
+    if (lane < 12 && wave < 8192) {
         uint32_t v = 0;
 #pragma unroll
         for (int i = 0; i < 12; ++i) v = lane == i ? (uint32_t)st_sum[i] : v;
-        reinterpret_cast<uint32_t*>(out + wave * 2)[lane] = v;
+        g_stamps[wave * 16 + lane] = v;
     }
 #endif
     // The last block to finish publishes the queue length for the worklist kernel and zeroes the two counters: a run
@@ -1579,3 +1590,9 @@ int launch_consensus(const TaxDev& tax, const HitsDev& hits, int strategy, blu_r
 }
 
 }  // namespace blu
+
+#if defined(BLU_EXPERIMENTS) && defined(BLU_X_STAMPS)
+extern "C" int blu_debug_stamps(uint32_t* dst, size_t n_words) {   // experiment builds only (scripts/stamps.py)
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(blu::g_stamps), n_words * sizeof(uint32_t), 0, hipMemcpyDeviceToHost);
+}
+#endif
