@@ -284,6 +284,11 @@ __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
 #define BLOCK_B 256
 #endif
 #define LONG_SPAN (1u << 28)    // rows one bit-score descriptor of the worklist kernel covers
+#ifndef BLU_B_WAVES_PER_SIMD
+#define BLU_B_WAVES_PER_SIMD 8   // worklist kernel: 64 VGPRs, 32 waves per CU (it hides memory round trips with waves, not with registers)
+#endif
+#define KEEP_ROWS 1024u         // worklist kernel: a segment of up to this many rows is held in registers (4 x 16 bytes per lane)
+#define SLOT_CAP 256u           // worklist kernel: rows of a top group collected before their side records are gathered
 #define TASK_SPAN (1ull << 27)   // rows one task's buffer descriptors cover
 #define CUT_LDS 512        // distinct cutoff values kept in LDS (4 KiB); larger tables are read from global memory
 #define ROW_MASK ((1u << BLU_ROW_BITS) - 1u)
@@ -1342,11 +1347,13 @@ __device__ __forceinline__ int select_reference(bool valid, uint32_t len, uint32
 }
 
 template <int STRAT, int LAYOUT>
-__global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
+__global__ __launch_bounds__(BLOCK_B, BLU_B_WAVES_PER_SIMD) void blu_consensus_long_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                  const uint32_t* __restrict__ worklist,
                                                                  const uint32_t* __restrict__ work_count) {
     constexpr bool PID32 = LAYOUT != 0, PACKED = LAYOUT == 2;
+    __shared__ uint32_t s_slot[BLOCK_B / WAVE][SLOT_CAP];   // rows of the top group found so far (segments kept in registers)
     const int lane = lane_id();
+    uint32_t* const slot = s_slot[__builtin_amdgcn_readfirstlane(threadIdx.x / WAVE)];
     const uint32_t n_work = work_count[2];   // queue length published by the stream kernel's last block
     const uint32_t wave = blockIdx.x * (blockDim.x / WAVE) + __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     const uint32_t n_waves = gridDim.x * (blockDim.x / WAVE);
@@ -1364,6 +1371,99 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
         const int32_t* c_aln = PACKED ? nullptr : h.align_len + start;
         const uint32_t* c_acc = PACKED ? nullptr : h.acc_rank + start;
         const u32x4* c_pk = PACKED ? reinterpret_cast<const u32x4*>(h.packed) + start : nullptr;   // 16-byte records
+        // group size, errors in file order, lane-local best key / shortest lineage / max pident (filled by either path below)
+        uint32_t k = 0, err_status = 0, err_row = 0;
+        uint32_t have = 0, b_len = 0, b_acc = 0, b_pos = 0, b_row = 0, l_minlen = 0xFFFFFFFFu;
+        uint32_t l_lo = 0xFFFFFFFFu, l_hi = 0;   // span of this lane's top rows in the sorted lineage order
+        uint32_t l_nan = 0xFFFFFFFFu;             // this lane's first top row with a NaN perc_identity (f64 layout only)
+        int b_aln = 0;
+        double b_pid = 0.0, l_maxpid = 0.0;
+        // The rows of the top group are collected in the slots (in no particular order) and their side records gathered one
+        // row per lane: one memory round trip per 64 top rows wherever they sit in the segment.  A lane's running best
+        // settles ties on all four keys by the row index (Relaxed: the later row, Cautious: the earlier one) — the rule
+        // the stable sort + .last() / .first() of find_multi_taxa_consensus.rs:39-68 amounts to.
+        uint32_t l_err_row = 0xFFFFFFFFu, l_err_kind = 0;   // this lane's first failing top row (parse_taxonomy Err, find_single_query_consensus.rs:58-60)
+        uint32_t kk = 0;                                     // slots in use (wave-uniform)
+        auto flush = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (uint32_t b = 0; b < kk; b += WAVE) {
+                const bool top = b + (uint32_t)lane < kk;
+                const uint32_t i = top ? slot[b + (uint32_t)lane] : 0u;
+                uint32_t tax, acc;
+                int aln;
+                double pid;
+                if (PACKED) { const u32x4 rec = c_pk[i]; tax = rec.x; pid = milli_to_f64(rec.y); aln = (int)rec.z; acc = rec.w; }
+                else { tax = c_tax[i]; pid = PID32 ? milli_to_f64(c_pm[i]) : c_pid[i]; aln = c_aln[i]; acc = c_acc[i]; }
+                const uint32_t pos = tax & ROW_MASK;
+                const bool unmatched = top && pos >= t.n_tax;
+                const uint32_t len = umin(tax >> BLU_ROW_BITS, t.max_depth);
+                const bool bad = top && !unmatched && len == 0;
+                const bool first_err = (unmatched | bad) && i < l_err_row;
+                l_err_kind = first_err ? (bad ? (uint32_t)BLU_ST_ERR_BAD_LINEAGE : (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID) : l_err_kind;
+                l_err_row = first_err ? i : l_err_row;
+                const bool gt = (len > b_len) | ((len == b_len) & ((pid > b_pid) | ((pid == b_pid) & ((aln > b_aln) | ((aln == b_aln) & (acc > b_acc))))));
+                const bool eq = (len == b_len) & (pid == b_pid) & (aln == b_aln) & (acc == b_acc);
+                const bool better = STRAT == BLU_RELAXED ? (gt | (eq & (i > b_pos))) : ((!gt & !eq) | (eq & (i < b_pos)));
+                const bool take = top & ((have == 0) | better);
+                have = top ? 1u : have;
+                b_len = take ? len : b_len;
+                b_pid = take ? pid : b_pid;
+                b_aln = take ? aln : b_aln;
+                b_acc = take ? acc : b_acc;
+                b_pos = take ? i : b_pos;
+                b_row = take ? pos : b_row;
+                l_minlen = top ? umin(l_minlen, len) : l_minlen;
+                l_lo = top ? umin(l_lo, pos) : l_lo;
+                l_hi = (top && pos > l_hi) ? pos : l_hi;
+                l_maxpid = (top && pid > l_maxpid) ? pid : l_maxpid;
+                if (!PID32) l_nan = (top && pid != pid) ? umin(l_nan, i) : l_nan;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            kk = 0;
+        };
+        auto collect = [&](const bool top, const uint32_t i) {   // one 64-row group of the segment: its top rows into the slots
+            const uint64_t mask = __ballot(top);
+            if (!mask) return;
+            if (top) slot[kk + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = i;
+            const uint32_t add = (uint32_t)__builtin_popcountll(mask);
+            kk += add;
+            k += add;
+            if (kk > SLOT_CAP - WAVE) flush();
+        };
+        if (n <= KEEP_ROWS) {
+            // ---- a segment of up to 1024 rows: one round trip for its bit-scores (four 16-byte loads per lane), the top score
+            // and the top rows come out of the registers
+            const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)c_bs, 0, n * 4u, 0x00020000);
+            u32x4 w[KEEP_ROWS / 256];
+#pragma unroll
+            for (uint32_t u = 0; u < KEEP_ROWS / 256; ++u) {
+                w[u] = u32x4{0u, 0u, 0u, 0u};
+                if (u * 256u < n) w[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (u * 256u + (uint32_t)lane * 4u) * 4u, 0, 0);
+            }
+            int m = INT_MIN;
+#pragma unroll
+            for (uint32_t u = 0; u < KEEP_ROWS / 256; ++u) {
+                const uint32_t i0 = u * 256u + (uint32_t)lane * 4u;
+                m = imax(m, i0 < n ? (int)w[u].x : INT_MIN);
+                m = imax(m, i0 + 1 < n ? (int)w[u].y : INT_MIN);
+                m = imax(m, i0 + 2 < n ? (int)w[u].z : INT_MIN);
+                m = imax(m, i0 + 3 < n ? (int)w[u].w : INT_MIN);
+            }
+            const int M = wave_max_i32(m);
+#pragma unroll
+            for (uint32_t u = 0; u < KEEP_ROWS / 256; ++u) {
+                if (u * 256u >= n) continue;      // (wave-uniform)
+                const uint32_t vv[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c) {
+                    const uint32_t i = u * 256u + (uint32_t)lane * 4u + c;
+                    collect(i < n && (int)vv[c] == M, i);
+                }
+            }
+        } else {
         // pass 1: top score
         // 16-byte loads, four per lane in flight (1024 rows per iteration); rows past the segment read as 0 from the
         // range-checked descriptor and are masked by index
@@ -1397,13 +1497,7 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
         const uint32_t w_first = wave_min_u32(m == M ? c_first : 0xFFFFFFFFu);
         const uint32_t w_last = wave_max_u32(m == M ? c_last : 0u);
         // pass 2: group size, errors in file order, lane-local best key / shortest lineage / max pident
-        uint32_t k = 0, err_status = 0, err_row = 0;
-        uint32_t have = 0, b_len = 0, b_acc = 0, b_pos = 0, b_row = 0, l_minlen = 0xFFFFFFFFu;
-        uint32_t l_lo = 0xFFFFFFFFu, l_hi = 0;   // span of this lane's top rows in the sorted lineage order
-        uint32_t l_nan = 0xFFFFFFFFu;             // this lane's first top row with a NaN perc_identity (f64 layout only)
-        int b_aln = 0;
-        double b_pid = 0.0, l_maxpid = 0.0;
-        for (uint64_t cb = w_first; cb <= w_last && cb < n && err_status == 0; cb += 1024) {
+        for (uint64_t cb = w_first; cb <= w_last && cb < n; cb += 1024) {
         {
         const uint64_t sb = cb / LONG_SPAN * LONG_SPAN;
         const uint32_t base = (uint32_t)(cb - sb);
@@ -1416,53 +1510,26 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
 #pragma unroll
               for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
           }
-          uint32_t it_err_row = 0xFFFFFFFFu, it_err_status = 0;   // first failing row of this round trip, in file order
           for (int u = 0; u < 4; ++u) {
             if (base + (uint32_t)u * 256 >= ns) break;
             const u32x4 cur = u == 0 ? v[0] : (u == 1 ? v[1] : (u == 2 ? v[2] : v[3]));
             const uint32_t vv[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-            const uint32_t iloc = base + (uint32_t)u * 256 + (uint32_t)lane * 4u + (uint32_t)c;
-            const bool top = iloc < ns && (int)vv[c] == M;
-            const uint64_t mask = __ballot(top);
-            if (!mask) continue;
-            k += (uint32_t)__builtin_popcountll(mask);
-            const uint32_t i = (uint32_t)sb + iloc;                   // row index inside the segment
-            const uint32_t ii = top ? i : 0;
-            uint32_t tax, acc;
-            int aln;
-            double pid;
-            if (PACKED) { const u32x4 rec = c_pk[ii]; tax = rec.x; pid = milli_to_f64(rec.y); aln = (int)rec.z; acc = rec.w; }
-            else { tax = c_tax[ii]; pid = PID32 ? milli_to_f64(c_pm[ii]) : c_pid[ii]; aln = c_aln[ii]; acc = c_acc[ii]; }
-            const uint32_t pos = tax & ROW_MASK;
-            const bool unmatched = top && pos >= t.n_tax;
-            const uint32_t len = umin(tax >> BLU_ROW_BITS, t.max_depth);
-            const bool bad = top && !unmatched && len == 0;
-            const uint64_t um = __ballot(unmatched), bm = __ballot(bad);
-            if (um | bm) {   // parse_taxonomy Err at the first failing row (find_single_query_consensus.rs:58-60)
-                const int fl = first_lane(um | bm);
-                const uint32_t cand = (uint32_t)sb + base + (uint32_t)u * 256 + (uint32_t)fl * 4u + (uint32_t)c;
-                if (cand < it_err_row) { it_err_row = cand; it_err_status = ((um >> fl) & 1) ? BLU_ST_ERR_UNMATCHED_TAXID : BLU_ST_ERR_BAD_LINEAGE; }
-                continue;
-            }
-            const bool take = top & ((have == 0) | key_better<STRAT>(len, pid, aln, acc, b_len, b_pid, b_aln, b_acc));
-            have = top ? 1u : have;
-            b_len = take ? len : b_len;
-            b_pid = take ? pid : b_pid;
-            b_aln = take ? aln : b_aln;
-            b_acc = take ? acc : b_acc;
-            b_pos = take ? i : b_pos;
-            b_row = take ? pos : b_row;
-            l_minlen = top ? umin(l_minlen, len) : l_minlen;
-            l_lo = top ? umin(l_lo, pos) : l_lo;
-            l_hi = (top && pos > l_hi) ? pos : l_hi;
-            l_maxpid = (top && pid > l_maxpid) ? pid : l_maxpid;
-            if (!PID32) l_nan = (top && pid != pid) ? umin(l_nan, i) : l_nan;
+                const uint32_t iloc = base + (uint32_t)u * 256 + (uint32_t)lane * 4u + (uint32_t)c;
+                collect(iloc < ns && (int)vv[c] == M, (uint32_t)sb + iloc);   // (row index inside the segment)
             }
           }
-          if (it_err_status) { err_status = it_err_status; err_row = it_err_row; }
         }
+        }
+        }   // (segments over KEEP_ROWS rows)
+        if (kk) flush();
+        {
+            const uint32_t first_err = wave_min_u32(l_err_row);
+            if (first_err != 0xFFFFFFFFu) {
+                err_row = first_err;
+                err_status = (uint32_t)rl((int)l_err_kind, first_lane(__ballot(l_err_row == first_err)));
+            }
         }
         if (err_status) {
             if (lane == 0) store_status(out, q, err_status, (uint32_t)start + err_row);
@@ -1494,8 +1561,14 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
         const double pid_ref = rl_f64(b_pid, rlane);
         const bool in_l = (uint32_t)lane < len_ref;
         const uint32_t lvl = in_l ? (uint32_t)lane : 0u;
-        const uint32_t shape_ref = t.lin[(uint64_t)row_ref * t.stride] >> 8;
+        // the span of the group is known here: its range-minimum lookup travels together with the reference row
+        const uint32_t minlen = wave_min_u32(l_minlen);
+        const uint32_t lo = wave_min_u32(l_lo), hi = wave_max_u32(l_hi);
+        const uint32_t hdr_ref = t.lin[(uint64_t)row_ref * t.stride];
         const uint32_t ref_node = t.lin[(uint64_t)row_ref * t.stride + BLU_ROW_NODE_BASE + lvl];
+        uint32_t d = minlen;
+        if (k != 1 && lo < hi) d = umin(minlen, shared_levels(t, lo, hi));   // levels shared by the whole top group (:137-180)
+        const uint32_t shape_ref = hdr_ref >> 8;
         const uint32_t packed = t.codes[(uint64_t)shape_ref * t.cstride + lvl];
         const double cut = t.cutvals[packed & ((1u << BLU_PACK_CUT_BITS) - 1u)];
         const uint32_t codes = packed_rank(packed) | (packed_mar(packed) << 16);
@@ -1509,11 +1582,6 @@ __global__ __launch_bounds__(BLOCK_B) void blu_consensus_long_kernel(HitsDev h, 
             if (lane == 0) store_result(out, q, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, reached, BLU_NONE_U16, ident_node, ref_row, A, pid_ref);
             continue;
         }
-        const uint32_t minlen = wave_min_u32(l_minlen);
-        // levels shared by the whole top group = range minimum of the adjacent-row LCP array over its span (:137-180)
-        const uint32_t lo = wave_min_u32(l_lo), hi = wave_max_u32(l_hi);
-        uint32_t d = minlen;
-        if (lo < hi) d = umin(minlen, shared_levels(t, lo, hi));
         const bool agree = d >= minlen;
         if (!agree && d == 0) { if (lane == 0) store_status(out, q, BLU_ST_ERR_ROOT_DISAGREE, ref_row); continue; }
         const uint32_t b = agree ? minlen - 1 : d - 1;

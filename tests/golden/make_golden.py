@@ -48,6 +48,33 @@ def main():
     with gzip.open(os.path.join(HERE, "zymo_mock_distilled.json.gz"), "wt", compresslevel=9) as f:
         json.dump(out, f, sort_keys=True, separators=(",", ":"))
 
+    # The same cases as BYTES: the text of each case's `taxon` object exactly as the reference wrote it
+    # (write_blutils_output.rs:138, serde_json::to_string_pretty), for pinning the product writer's layout.
+    raw = open(src).read()
+    texts = {}
+    for m in re.finditer(r'\n      "query": "([^"]*)",\n      "taxon": \{\n', raw):
+        start = m.end() - 2                       # the opening brace
+        depth, i = 0, start
+        while True:
+            ch = raw[i]
+            if ch == '"':                         # skip a string (no escapes to worry about beyond \" in this file)
+                i += 1
+                while raw[i] != '"':
+                    i += 2 if raw[i] == "\\" else 1
+            elif ch == "{":
+                depth += 1
+            elif ch == "}":
+                depth -= 1
+                if depth == 0:
+                    break
+            i += 1
+        texts[m.group(1)] = raw[start:i + 1]
+    with gzip.open(os.path.join(HERE, "zymo_mock_taxon_text.json.gz"), "wt", compresslevel=9) as f:
+        json.dump({"source": out["source"], "indent": "the objects sit at 6 spaces of indentation, as in the document",
+                   "text_of": {e["example_query"]: texts[e["example_query"]] for e in out["cases"]}}, f, sort_keys=True)
+    for e in out["cases"]:
+        assert json.loads(texts[e["example_query"]]) == e["taxon"]
+
     # worked example from the user guide: the JSON block inside the markdown
     md = open(os.path.join(REF, "docs/book/02_run_blast_and_generate_consensus_identities.md")).read()
     m = re.search(r"```bash\n(\{\n  \"results\": \[.*?\n\})\n```", md, re.S)

@@ -213,3 +213,61 @@ def test_parallel_ingest_and_render_are_deterministic(tmp_path):
         docs.append(re.sub(r'"runId": "[0-9a-f-]+"', '"runId": "x"', raw))
     assert docs[0] == docs[1]
     assert len(json.loads(docs[0])["results"]) == 6000
+
+
+def test_golden_taxon_objects_leave_the_product_writer_byte_for_byte(tmp_path, golden_dir):
+    """The reference's only real output (test/mock/output/zymo-mock/blutils.consensus.json, serde_json::to_string_pretty,
+    write_blutils_output.rs:138) against the PRODUCT writer: the 253 distinct `taxon` objects are turned back into input
+    FILES by the reconstruction recipe (tests/golden_recipe.py: one row per bean occurrence), the library builds the
+    document from them, and every object that comes back with the same content must come back as the same BYTES as the
+    reference wrote (key order, indentation, `845.0`, `null`, nested bean arrays).  Content equality itself is limited by
+    the recipe (the beans keep one lineage per key), hence the floor on the count rather than 253."""
+    import gzip
+    with gzip.open(os.path.join(golden_dir, "zymo_mock_distilled.json.gz"), "rt") as f:
+        cases = json.load(f)["cases"]
+    with gzip.open(os.path.join(golden_dir, "zymo_mock_taxon_text.json.gz"), "rt") as f:
+        text_of = json.load(f)["text_of"]
+    lineages, rows = {}, []
+    for i, c in enumerate(cases):
+        t = c["taxon"]
+        for bean in t["consensusBeans"]:
+            taxid = lineages.setdefault(bean["taxonomy"], 1000 + len(lineages))
+            for k in range(int(bean["occurrences"])):
+                acc = bean["accessions"][min(k, len(bean["accessions"]) - 1)]
+                rows.append(f"case{i:04d}\t{acc}\t{taxid}\t{t['percIdentity']:.3f}\t400\t0\t0\t1\t400\t1\t400\t1e-50\t{int(t['bitScore'])}")
+    (tmp_path / "b.tsv").write_text("\n".join(rows) + "\n")
+    (tmp_path / "t.json").write_text(json.dumps({"blutilsVersion": "7.1.3", "sourceDatabase": "golden", "taxonomies": [
+        {"taxid": v, "rank": "", "numericLineage": k, "textLineage": k, "accessions": []} for k, v in lineages.items()]}))
+    raw, _ = pipeline.build_consensus_identities(str(tmp_path / "b.tsv"), str(tmp_path / "t.json"), "bacteria", "relaxed", parse=False)
+    doc = json.loads(raw)
+    assert [r["query"] for r in doc["results"]] == [f"case{i:04d}" for i in range(len(cases))]
+
+    def taxon_text(i):
+        at = raw.index(f'"query": "case{i:04d}",\n      "taxon": ') + len(f'"query": "case{i:04d}",\n      "taxon": ')
+        depth, j, in_str = 0, at, False
+        while True:
+            ch = raw[j]
+            if in_str:
+                if ch == "\\":
+                    j += 1
+                elif ch == '"':
+                    in_str = False
+            elif ch == '"':
+                in_str = True
+            elif ch == "{":
+                depth += 1
+            elif ch == "}":
+                depth -= 1
+                if depth == 0:
+                    return raw[at:j + 1]
+            j += 1
+
+    same_content = same_bytes = 0
+    for i, c in enumerate(cases):
+        if doc["results"][i]["taxon"] == c["taxon"]:
+            same_content += 1
+            got, want = taxon_text(i), text_of[c["example_query"]]
+            assert got == want, (c["example_query"], got[:300], want[:300])
+            same_bytes += 1
+    print(f"[golden writer] {same_content} of {len(cases)} objects reproduce in content, {same_bytes} of them byte for byte")
+    assert same_bytes == same_content and same_bytes >= 100
