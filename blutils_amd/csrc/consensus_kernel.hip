@@ -273,6 +273,7 @@ __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
 }
 
 #define META_SLOW 0x80000000u
+#define KEY_PID_BITS 17u         // milli-percent perc_identity below 2^17 packs with the lineage length into one sort word
 #ifndef SHORT_SEG
 #define SHORT_SEG 128u           // segments up to here are streamed (4 .. 32 lanes per query); longer ones take the sparse long pass
 #endif
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         load_seg(next_task, nx_off, nx_end);        // consumed after this task's phase 1 (prefetch decision) and by the next iteration
         asm volatile("" ::: "memory");              // (keeps these loads in front of the ring requests below: the counted waits rely on it)
         uint32_t fill = 0;   // wave-uniform: entries used in the LDS list
+        bool keyed = false;  // wave-uniform: the list of this round holds comparison-ready entries (see gather_list)
         bool in_span = true;
         // One buffer descriptor per column, based at the task's first row and TASK_SPAN rows long: 32-bit lane byte
         // offsets (< 2^31 also for the 8-byte column), no 64-bit VALU address math, and the hardware range check
@@ -940,11 +942,24 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 }
             }
             between();
+            // Milli-percent layouts: the entries go to the list ready to be compared — lineage length clamped, (length,
+            // perc_identity) as ONE word (length << 17 | milli-percent: the first two sort keys of
+            // find_multi_taxa_consensus.rs:39-68), align_length biased to compare unsigned.  A perc_identity that does not
+            // fit 17 bits (> 131 %: not BLAST output) keeps the round on the plain records.
+            bool ovf = false;
+            if (PID32) {
+#pragma unroll
+                for (int u = 0; u < NG; ++u) ovf |= ((uint32_t)u * WAVE + (uint32_t)lane < fill) && g[u].y >= (1u << KEY_PID_BITS);
+            }
+            keyed = PID32 && __ballot(ovf) == 0ull;
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
                 const uint32_t idx = (uint32_t)u * WAVE + (uint32_t)lane;
                 if (idx < fill) {
-                    L.rec[idx] = make_uint4(g[u].x, g[u].y, g[u].z, g[u].w);
+                    if (keyed) {
+                        const uint32_t len = umin(g[u].x >> BLU_ROW_BITS, t.max_depth);
+                        L.rec[idx] = make_uint4((g[u].x & ROW_MASK) | (len << BLU_ROW_BITS), (len << KEY_PID_BITS) | g[u].y, g[u].z ^ 0x80000000u, g[u].w);
+                    } else L.rec[idx] = make_uint4(g[u].x, g[u].y, g[u].z, g[u].w);
                     L.pq[idx] = (uint16_t)gpos[u];
                     if (!PID32) L.p1[idx] = ghi[u];
                 }
@@ -977,6 +992,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         fill = 0;
         stop_q = WAVE;
         bool ring_round = false;
+        keyed = false;
         {
             const uint32_t rows = L.seg[lane].y;                    // this lane's query (0: empty, done, too long, or outside the span)
             const uint64_t live = __ballot(rows != 0u);
@@ -1081,33 +1097,70 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             uint32_t b_len = 0, b_acc = 0, lo = 0xFFFFFFFFu, hi = 0, l_minlen = 0xFFFFFFFFu, l_row = 0, l_pos = 0;
             int b_aln = 0;
             PK b_pid = 0, l_maxpid = 0;   // fold(0.0, max): find_multi_taxa_consensus.rs:182-185
-#pragma unroll 2
-            for (uint32_t e = 0; e < kmax; ++e) {
-                const uint32_t idx = first + (e < k ? e : (k ? k - 1u : 0u));
-                const uint4 x = L.rec[idx];              // {row id, pident, align_len, accession rank}
-                const uint32_t xpos = L.pq[idx];
-                const uint32_t len = umin(x.x >> BLU_ROW_BITS, t.max_depth), pos = x.x & ROW_MASK;
-                const bool unmatched = pos >= t.n_tax, bad = (x.x >> BLU_ROW_BITS) == 0;
-                const bool first_err = (err == 0) & (unmatched | bad);
-                err = first_err ? (unmatched ? (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID : (uint32_t)BLU_ST_ERR_BAD_LINEAGE) : err;
-                err_pos = first_err ? xpos : err_pos;
-                PK xpid;
-                if constexpr (PID32) xpid = x.y;
-                else {
-                    xpid = __hiloint2double((int)L.p1[idx], (int)x.y);
-                    nan_pos = (nan_pos == 0xFFFFFFFFu && xpid != xpid) ? xpos : nan_pos;
+            const uint32_t last_e = k ? k - 1u : 0u;
+            uint4 nx_rec = L.rec[first];                 // (entry e + 1 is read while entry e is worked on)
+            uint32_t nx_pq = L.pq[first];
+            if (PID32 && keyed) {
+                uint64_t BK = 0;                         // best (length, perc_identity, align_length) so far
+                uint32_t kmin = 0xFFFFFFFFu, pmax = 0;
+                for (uint32_t e = 0; e < kmax; ++e) {
+                    const uint4 x = nx_rec;
+                    const uint32_t xpos = nx_pq;
+                    const uint32_t idn = first + (e + 1u < k ? e + 1u : last_e);
+                    nx_rec = L.rec[idn];
+                    nx_pq = L.pq[idn];
+                    const uint32_t pos = x.x & ROW_MASK;
+                    const bool unmatched = pos >= t.n_tax, bad = x.x < (1u << BLU_ROW_BITS);
+                    const bool first_err = (err == 0) & (unmatched | bad);
+                    err = first_err ? (unmatched ? (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID : (uint32_t)BLU_ST_ERR_BAD_LINEAGE) : err;
+                    err_pos = first_err ? xpos : err_pos;
+                    kmin = umin(kmin, x.y);
+                    lo = umin(lo, pos);
+                    hi = pos > hi ? pos : hi;
+                    const uint32_t pm = x.y & ((1u << KEY_PID_BITS) - 1u);
+                    pmax = pm > pmax ? pm : pmax;
+                    const uint64_t K = ((uint64_t)x.y << 32) | x.z;
+                    const bool gt = (K > BK) | ((K == BK) & (x.w > b_acc)), eq = (K == BK) & (x.w == b_acc);
+                    const bool take = (e == 0) | (STRAT == BLU_RELAXED ? (gt | eq) : !(gt | eq));
+                    BK = take ? K : BK;
+                    b_acc = take ? x.w : b_acc;
+                    l_row = take ? pos : l_row;
+                    l_pos = take ? xpos : l_pos;
                 }
-                l_minlen = umin(l_minlen, len);
-                lo = umin(lo, pos);
-                hi = pos > hi ? pos : hi;
-                l_maxpid = xpid > l_maxpid ? xpid : l_maxpid;
-                const bool take = (e == 0) | key_better<STRAT, PK>(len, xpid, (int)x.z, x.w, b_len, b_pid, b_aln, b_acc);
-                b_len = take ? len : b_len;
-                b_pid = take ? xpid : b_pid;
-                b_aln = take ? (int)x.z : b_aln;
-                b_acc = take ? x.w : b_acc;
-                l_row = take ? pos : l_row;
-                l_pos = take ? xpos : l_pos;
+                const uint32_t k1 = (uint32_t)(BK >> 32);
+                b_len = k1 >> KEY_PID_BITS;
+                l_minlen = kmin >> KEY_PID_BITS;
+                if constexpr (PID32) { b_pid = k1 & ((1u << KEY_PID_BITS) - 1u); l_maxpid = pmax; }
+            } else {
+                for (uint32_t e = 0; e < kmax; ++e) {
+                    const uint4 x = nx_rec;              // {row id, pident, align_len, accession rank}
+                    const uint32_t xpos = nx_pq;
+                    const uint32_t idx = first + (e < k ? e : last_e), idn = first + (e + 1u < k ? e + 1u : last_e);
+                    nx_rec = L.rec[idn];
+                    nx_pq = L.pq[idn];
+                    const uint32_t len = umin(x.x >> BLU_ROW_BITS, t.max_depth), pos = x.x & ROW_MASK;
+                    const bool unmatched = pos >= t.n_tax, bad = (x.x >> BLU_ROW_BITS) == 0;
+                    const bool first_err = (err == 0) & (unmatched | bad);
+                    err = first_err ? (unmatched ? (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID : (uint32_t)BLU_ST_ERR_BAD_LINEAGE) : err;
+                    err_pos = first_err ? xpos : err_pos;
+                    PK xpid;
+                    if constexpr (PID32) xpid = x.y;
+                    else {
+                        xpid = __hiloint2double((int)L.p1[idx], (int)x.y);
+                        nan_pos = (nan_pos == 0xFFFFFFFFu && xpid != xpid) ? xpos : nan_pos;
+                    }
+                    l_minlen = umin(l_minlen, len);
+                    lo = umin(lo, pos);
+                    hi = pos > hi ? pos : hi;
+                    l_maxpid = xpid > l_maxpid ? xpid : l_maxpid;
+                    const bool take = (e == 0) | key_better<STRAT, PK>(len, xpid, (int)x.z, x.w, b_len, b_pid, b_aln, b_acc);
+                    b_len = take ? len : b_len;
+                    b_pid = take ? xpid : b_pid;
+                    b_aln = take ? (int)x.z : b_aln;
+                    b_acc = take ? x.w : b_acc;
+                    l_row = take ? pos : l_row;
+                    l_pos = take ? xpos : l_pos;
+                }
             }
             if (pend) {
                 bool done = true;
