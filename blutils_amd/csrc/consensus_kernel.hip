@@ -1098,17 +1098,13 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             int b_aln = 0;
             PK b_pid = 0, l_maxpid = 0;   // fold(0.0, max): find_multi_taxa_consensus.rs:182-185
             const uint32_t last_e = k ? k - 1u : 0u;
-            uint4 nx_rec = L.rec[first];                 // (entry e + 1 is read while entry e is worked on)
-            uint32_t nx_pq = L.pq[first];
+            uint4 nx_rec = make_uint4(0, 0, 0, 0);
+            uint32_t nx_pq = 0;
+            if (!(PID32 && keyed)) { nx_rec = L.rec[first]; nx_pq = L.pq[first]; }   // (generic loop: entry e + 1 is read while entry e is worked on)
             if (PID32 && keyed) {
                 uint64_t BK = 0;                         // best (length, perc_identity, align_length) so far
                 uint32_t kmin = 0xFFFFFFFFu, pmax = 0;
-                for (uint32_t e = 0; e < kmax; ++e) {
-                    const uint4 x = nx_rec;
-                    const uint32_t xpos = nx_pq;
-                    const uint32_t idn = first + (e + 1u < k ? e + 1u : last_e);
-                    nx_rec = L.rec[idn];
-                    nx_pq = L.pq[idn];
+                auto step = [&](const uint4 x, const uint32_t xpos, const bool is_first) {
                     const uint32_t pos = x.x & ROW_MASK;
                     const bool unmatched = pos >= t.n_tax, bad = x.x < (1u << BLU_ROW_BITS);
                     const bool first_err = (err == 0) & (unmatched | bad);
@@ -1121,11 +1117,24 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     pmax = pm > pmax ? pm : pmax;
                     const uint64_t K = ((uint64_t)x.y << 32) | x.z;
                     const bool gt = (K > BK) | ((K == BK) & (x.w > b_acc)), eq = (K == BK) & (x.w == b_acc);
-                    const bool take = (e == 0) | (STRAT == BLU_RELAXED ? (gt | eq) : !(gt | eq));
+                    const bool take = is_first | (STRAT == BLU_RELAXED ? (gt | eq) : !(gt | eq));
                     BK = take ? K : BK;
                     b_acc = take ? x.w : b_acc;
                     l_row = take ? pos : l_row;
                     l_pos = take ? xpos : l_pos;
+                };
+                // four entries per trip, their LDS reads issued together: one read latency per four entries
+                for (uint32_t e = 0; e < kmax; e += 4) {
+                    uint4 x[4];
+                    uint32_t xp[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const uint32_t idx = first + (e + j < k ? e + j : last_e);
+                        x[j] = L.rec[idx];
+                        xp[j] = L.pq[idx];
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) step(x[j], xp[j], e == 0 && j == 0);
                 }
                 const uint32_t k1 = (uint32_t)(BK >> 32);
                 b_len = k1 >> KEY_PID_BITS;
