@@ -42,16 +42,23 @@ def c3_table():
     torch.cuda.empty_cache()
 
 
-def _permute_rows(hits, idx):
-    """Rows of every column (or 16-byte side record) gathered by idx; seg_off untouched."""
+def _reverse_queries(hits, n_queries, hits_per_query):
+    """The table with the order of whole queries reversed (rows inside a query keep file order); seg_off untouched.
+    Done in slices of 2^18 queries: torch's indexing kernels misplace rows of a tensor of more than 2^31 elements (the
+    8 GB packed column) on this stack — a property of the harness, found when this test first ran on the packed layout."""
+    import torch
     out = {}
     for k, v in hits.items():
         if k == "seg_off":
             out[k] = v
-        elif k == "packed":
-            out[k] = v.view(-1, 4)[idx].contiguous().view(-1)
-        else:
-            out[k] = v[idx].contiguous()
+            continue
+        width = hits_per_query * (4 if k == "packed" else 1)
+        src = v.view(n_queries, width)
+        dst = torch.empty_like(src)
+        for a in range(0, n_queries, 1 << 18):
+            b = min(n_queries, a + (1 << 18))
+            dst[n_queries - b:n_queries - a] = src[a:b].flip(0)
+        out[k] = dst.view(-1)
     return out
 
 
@@ -88,15 +95,15 @@ def test_c3_full_size_properties(c3_table, layout):
     assert np.concatenate(parts).tobytes() == whole.tobytes()
     del parts
     # --- permutation equivariance: reverse the order of whole queries (rows inside a query keep file order)
-    idx = torch.arange(Hn, device="cuda").view(Q, 50).flip(0).reshape(-1)
-    rev = _permute_rows(hits, idx)
+    rev = _reverse_queries(hits, Q, 50)
+    assert bool((rev["bitscore"][:50] == hits["bitscore"][-50:]).all()) and bool((rev["bitscore"][-50:] == hits["bitscore"][:50]).all())
     got = run(rev, Q)
     exp = whole[::-1].copy()
     has = exp["ref_row"] != 0xFFFFFFFF
     qidx = np.nonzero(has)[0]
     exp["ref_row"][has] = (qidx * 50 + exp["ref_row"][has] % 50).astype(np.uint32)
     assert got.tobytes() == exp.tobytes()
-    del rev, idx, got, exp
+    del rev, got, exp
     # --- scattered windows against the oracle
     rng = np.random.default_rng(5)
     for q0 in rng.integers(0, Q - 2500, 40):
