@@ -273,6 +273,7 @@ __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
 }
 
 #define META_SLOW 0x80000000u
+#define META_DENSE 0x40000000u   // the query was reduced by a dense step of phase 1: nothing of it in the list
 #define KEY_PID_BITS 17u         // milli-percent perc_identity below 2^17 packs with the lineage length into one sort word
 #ifndef SHORT_SEG
 #define SHORT_SEG 128u           // segments up to here are streamed (4 .. 32 lanes per query); longer ones take the sparse long pass
@@ -458,6 +459,17 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         asm volatile("" ::: "memory");              // (keeps these loads in front of the ring requests below: the counted waits rely on it)
         uint32_t fill = 0;   // wave-uniform: entries used in the LDS list
         bool keyed = false;  // wave-uniform: the list of this round holds comparison-ready entries (see gather_list)
+        // per-lane (= per-query) results of phase 2a
+        // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
+        const uint64_t q = q0 + (uint32_t)lane;
+        const uint32_t row0 = (uint32_t)my_off;
+        uint32_t mode = 3, r_len = 0, r_row = 0, r_pos = 0, r_hdr = 0, minlen = 0, d = 0, rec_kind = 0, g_lo = 0, g_hi = 0;
+        typedef typename PidKey<PID32>::type PK;
+        PK r_pid = 0, max_pid = 0;   // fold(0.0, max): find_multi_taxa_consensus.rs:182-185
+        uint4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+        // a query reduced by a dense step (below): 0 no, 1 result in the variables above, 2 parse error in (dn_err, dn_pos),
+        // 3 hand to the worklist kernel (a perc_identity that does not fit the packed key)
+        uint32_t dn_flag = 0, dn_err = 0, dn_pos = 0, dn_k = 0;
         bool in_span = true;
         // One buffer descriptor per column, based at the task's first row and TASK_SPAN rows long: 32-bit lane byte
         // offsets (< 2^31 also for the 8-byte column), no 64-bit VALU address math, and the hardware range check
@@ -856,6 +868,107 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 if (LPQ >= 4) gk += (uint32_t)dpp<0x4E>((int)gk);
                 if (LPQ >= 8) gk += (uint32_t)dpp<0x141>((int)gk);
                 if (LPQ >= 16) gk += (uint32_t)dpp<0x140>((int)gk);
+                if (PID32 && k0 + k1 + k2 + k3 > CAP) {
+                    // ---- a DENSE step: the top rows of this step alone would not fit an empty list (many hits tie on the top
+                    // score — identical database sequences).  No list: every lane fetches the side records of ITS OWN top rows,
+                    // four requests in flight, and reduces them as they come; the lanes of a query then merge (DPP) and the
+                    // result goes to the query's lane of phase 2 (ds_bpermute).  Same rule as phase 2a: the reference row is
+                    // the maximum (Relaxed) / minimum (Cautious) of (length, perc_identity, align_length, accession), full ties
+                    // settled by the position in the file (the later / the earlier row).
+                    uint64_t BK = 0;
+                    uint32_t bacc = 0, bpos = 0, brow = 0, kmin = 0xFFFFFFFFu, pmax = 0, dlo = 0xFFFFFFFFu, dhi = 0;
+                    uint32_t e_pos = 0xFFFFFFFFu, e_kind = 0, have = 0, ovf = 0;
+                    auto better = [&](const uint64_t K, const uint32_t acc, const uint32_t pos, const uint64_t K2, const uint32_t acc2, const uint32_t pos2) {
+                        const bool gt = (K > K2) | ((K == K2) & (acc > acc2)), eq = (K == K2) & (acc == acc2);
+                        return STRAT == BLU_RELAXED ? (gt | (eq & (pos > pos2))) : ((!gt & !eq) | (eq & (pos < pos2)));
+                    };
+                    uint32_t m = mask;
+                    while (__ballot(m != 0u)) {
+                        u32x4 g[4];
+                        uint32_t gp[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool on = m != 0u;
+                            const uint32_t hb = on ? 31u - (uint32_t)__builtin_clz(m) : 0u, i = RPL - 1u - hb;   // (mask bit RPL - 1 - i = row i: file order)
+                            m = on ? (m & ~(1u << hb)) : 0u;
+                            gp[j] = on ? sub + i : 0xFFFFFFFFu;
+                            const uint32_t row = row0 + i;
+                            if (PACKED) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, on ? row * 16u : 0xFFFFFFC0u, 0, GATHER_AUX);
+                            else {
+                                const uint32_t o4 = on ? row * 4u : 0xFFFFFFF0u;
+                                g[j].x = __builtin_amdgcn_raw_buffer_load_b32(rs_tax, o4, 0, GATHER_AUX);
+                                g[j].y = __builtin_amdgcn_raw_buffer_load_b32(rs_pid, o4, 0, GATHER_AUX);
+                                g[j].z = __builtin_amdgcn_raw_buffer_load_b32(rs_aln, o4, 0, GATHER_AUX);
+                                g[j].w = __builtin_amdgcn_raw_buffer_load_b32(rs_acc, o4, 0, GATHER_AUX);
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool on = gp[j] != 0xFFFFFFFFu;
+                            const uint32_t len = umin(g[j].x >> BLU_ROW_BITS, t.max_depth), pos = g[j].x & ROW_MASK;
+                            const bool unmatched = on && pos >= t.n_tax, bad = on && !unmatched && (g[j].x >> BLU_ROW_BITS) == 0;
+                            const bool ferr = (unmatched | bad) && gp[j] < e_pos;
+                            e_kind = ferr ? (bad ? (uint32_t)BLU_ST_ERR_BAD_LINEAGE : (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID) : e_kind;
+                            e_pos = ferr ? gp[j] : e_pos;
+                            ovf |= (on && g[j].y >= (1u << KEY_PID_BITS)) ? 1u : 0u;
+                            const uint32_t k1 = (len << KEY_PID_BITS) | (g[j].y & ((1u << KEY_PID_BITS) - 1u));
+                            const uint64_t K = ((uint64_t)k1 << 32) | (g[j].z ^ 0x80000000u);
+                            const bool take = on & ((have == 0u) | better(K, g[j].w, gp[j], BK, bacc, bpos));
+                            have = on ? 1u : have;
+                            BK = take ? K : BK; bacc = take ? g[j].w : bacc; bpos = take ? gp[j] : bpos; brow = take ? pos : brow;
+                            kmin = on ? umin(kmin, k1) : kmin;
+                            const uint32_t pm = g[j].y & ((1u << KEY_PID_BITS) - 1u);
+                            pmax = (on && pm > pmax) ? pm : pmax;
+                            dlo = on ? umin(dlo, pos) : dlo;
+                            dhi = (on && pos > dhi) ? pos : dhi;
+                        }
+                    }
+                    // merge the lanes of a query (2, 4 or 8 of them: quad_perm swaps, then the half-row mirror)
+                    auto merge = [&](auto ctrl) {
+                        constexpr int C = decltype(ctrl)::value;
+                        const uint64_t K2 = ((uint64_t)(uint32_t)dpp<C>((int)(uint32_t)(BK >> 32)) << 32) | (uint32_t)dpp<C>((int)(uint32_t)BK);
+                        const uint32_t acc2 = (uint32_t)dpp<C>((int)bacc), pos2 = (uint32_t)dpp<C>((int)bpos), row2 = (uint32_t)dpp<C>((int)brow);
+                        const uint32_t have2 = (uint32_t)dpp<C>((int)have);
+                        const bool take = (have2 != 0u) & ((have == 0u) | better(K2, acc2, pos2, BK, bacc, bpos));
+                        BK = take ? K2 : BK; bacc = take ? acc2 : bacc; bpos = take ? pos2 : bpos; brow = take ? row2 : brow;
+                        have |= have2;
+                        kmin = umin(kmin, (uint32_t)dpp<C>((int)kmin));
+                        const uint32_t pm2 = (uint32_t)dpp<C>((int)pmax); pmax = pm2 > pmax ? pm2 : pmax;
+                        dlo = umin(dlo, (uint32_t)dpp<C>((int)dlo));
+                        const uint32_t hi2 = (uint32_t)dpp<C>((int)dhi); dhi = hi2 > dhi ? hi2 : dhi;
+                        const uint32_t ep2 = (uint32_t)dpp<C>((int)e_pos), ek2 = (uint32_t)dpp<C>((int)e_kind);
+                        e_kind = ep2 < e_pos ? ek2 : e_kind; e_pos = umin(e_pos, ep2);
+                        ovf |= (uint32_t)dpp<C>((int)ovf);
+                    };
+                    if (LPQ >= 2) merge(std::integral_constant<int, 0xB1>());
+                    if (LPQ >= 4) merge(std::integral_constant<int, 0x4E>());
+                    if (LPQ >= 8) merge(std::integral_constant<int, 0x141>());
+                    if (LPQ >= 16) merge(std::integral_constant<int, 0x140>());
+                    // the query's lane of phase 2 (lane = query) fetches the result from the first lane of the query's group
+                    const uint32_t tq = (uint32_t)lane;                               // this lane as a query of the task
+                    const bool mine = tq >= qb && tq < qn && tq < nq;
+                    const int src = (int)(((mine ? tq - qb : 0u) * LPQ) * 4u);          // byte address of the source lane
+                    const uint32_t f_klo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)BK);
+                    const uint32_t f_khi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(BK >> 32));
+                    const uint32_t f_pos = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)bpos), f_row = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)brow);
+                    const uint32_t f_kmin = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)kmin), f_pmax = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pmax);
+                    const uint32_t f_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dlo), f_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dhi);
+                    const uint32_t f_epos = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)e_pos), f_ekind = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)e_kind);
+                    const uint32_t f_have = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)have), f_ovf = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ovf);
+                    const uint32_t f_gk = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)gk);
+                    (void)f_klo;
+                    if (mine && f_have) {
+                        if (f_ovf) dn_flag = 3;
+                        else if (f_epos != 0xFFFFFFFFu) { dn_flag = 2; dn_err = f_ekind; dn_pos = f_epos; }
+                        else {
+                            dn_flag = 1; dn_k = f_gk;
+                            if constexpr (PID32) { r_pid = f_khi & ((1u << KEY_PID_BITS) - 1u); max_pid = f_pmax; }
+                            r_len = f_khi >> KEY_PID_BITS; r_row = f_row; r_pos = f_pos; minlen = f_kmin >> KEY_PID_BITS; g_lo = f_lo; g_hi = f_hi;
+                        }
+                    }
+                    if (sub == 0 && gk != 0u) L.meta[qi] = META_DENSE;
+                    continue;
+                }
                 uint32_t idx = rbase + incl - c;                      // list slot of this lane's first top row (file order)
                 if (!fits) {
                     // The list is full.  The queries of this step whose top rows still fit are taken (slots go in query
@@ -965,15 +1078,6 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 }
             }
         };
-        // per-lane (= per-query) results of phase 2a
-        // mode: 0 multi, 2 single, 3 finished (empty / error / handed to the worklist)
-        const uint64_t q = q0 + (uint32_t)lane;
-        const uint32_t row0 = (uint32_t)my_off;
-        // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
-        uint32_t mode = 3, r_len = 0, r_row = 0, r_pos = 0, r_hdr = 0, minlen = 0, d = 0, rec_kind = 0, g_lo = 0, g_hi = 0;
-        typedef typename PidKey<PID32>::type PK;
-        PK r_pid = 0, max_pid = 0;   // fold(0.0, max): find_multi_taxa_consensus.rs:182-185
-        uint4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
         // Phase 1 and phase 2a run in ROUNDS: a round compacts the top rows of as many pending queries as the LDS list holds
         // (the steps that do not fit are marked and come again), phase 2a reduces them, the list is reused.  With small
         // top groups (the usual case) everything fits and there is one round; with many ties per query — identical
@@ -1087,7 +1191,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         {
             const uint64_t nrows = my_end - my_off;
             const uint32_t m = L.meta[lane];
-            const bool listed = pend && nrows != 0 && nrows <= MAX_TASK_SEG && in_span && !(m & META_SLOW) && !BLU_X_SKIP_2A;
+            const bool listed = pend && nrows != 0 && nrows <= MAX_TASK_SEG && in_span && !(m & (META_SLOW | META_DENSE)) && !BLU_X_SKIP_2A;
             const uint32_t first = listed ? (m & 0xFFFFu) : 0u, k = listed ? ((m >> 16) & 0x3FFu) : 0u;
             const uint32_t kmax = wave_max_u32(k);
             // parse errors in file order (find_single_query_consensus.rs:51-64), then NaN perc_identity; reference row,
@@ -1176,6 +1280,9 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 if (nrows == 0) { pack_status(ra, rb, BLU_ST_NO_HITS, 0xFFFFFFFFu); rec_kind = 1; }   // mod.rs:107-113
                 else if (nrows > MAX_TASK_SEG || !in_span) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
                 else if (m & META_SLOW) done = false;   // its step did not fit the list this round: again in the next one
+                else if (dn_flag == 1) mode = dn_k == 1 ? 2u : 0u;                                    // reduced by a dense step
+                else if (dn_flag == 2) { pack_status(ra, rb, dn_err, row0 + dn_pos); rec_kind = 1; }
+                else if (dn_flag == 3) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
                 else if (BLU_X_SKIP_2A) { mode = 2; r_row = L.rec[m & 0xFF].x & ROW_MASK; r_len = 5; minlen = 5; }
                 else if (err) { pack_status(ra, rb, err, row0 + err_pos); rec_kind = 1; }
                 else if (!PID32 && nan_pos != 0xFFFFFFFFu) { pack_status(ra, rb, BLU_ST_ERR_BAD_PIDENT, row0 + nan_pos); rec_kind = 1; }

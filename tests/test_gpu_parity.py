@@ -668,3 +668,34 @@ def test_worklist_kernel_score_orders(order):
         got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy,
                                         pident_milli=milli, packed=True)
         _assert_records_equal(got, exp)
+
+
+@pytest.mark.parametrize("hits_per_query", [4, 10, 20, 50, 100])
+def test_dense_top_groups_in_short_segments(hits_per_query):
+    """Many hits tie on the top score in segments the stream kernel's ring path takes (identical database sequences): a
+    step whose top rows would not fit an empty list is reduced by the lanes that scanned it (dense step), the others go
+    through the list in rounds.  Whole-segment ties, half-segment ties and a mix, few distinct values on every sort key
+    (so the stable-sort tie rule decides), unmatched rows in the groups; both strategies, milli-percent and packed layouts."""
+    rng = np.random.default_rng(100 + hits_per_query)
+    tax = synth.make_taxonomy(3000, 31)
+    t = _engine_tax(tax, "custom", H.CUSTOM_16S)
+    nq = 1500
+    h = synth.make_hits(tax, nq, 500 + hits_per_query, hits_per_query, p_unmatched=0.002).numpy()
+    bs = h["bitscore"].reshape(nq, hits_per_query)
+    kind = rng.integers(0, 3, nq)                                   # 0: every row tied, 1: the first half tied, 2: as generated
+    top = bs.max(axis=1)
+    bs[kind == 0, :] = top[kind == 0, None]
+    half = max(1, hits_per_query // 2)
+    bs[kind == 1, :half] = top[kind == 1, None]
+    h["pident"][:] = np.round(h["pident"] / 4) * 4                   # few distinct values: deep tie-breaks
+    h["align_len"][:] = 400 + h["align_len"] % 2
+    h["acc_rank"][:] = h["acc_rank"] % 3
+    rows = t.engine_rows(h["tax_row"])
+    pm = np.round(h["pident"] * 1000).astype(np.uint32)
+    for strategy in ("relaxed", "cautious"):
+        exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S, threads=8)
+        for packed in (False, True):
+            got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy=strategy,
+                                            pident_milli=pm, packed=packed)
+            _assert_records_equal(got, exp)
+    assert (exp["status"] == 0).sum() > 500
