@@ -47,7 +47,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     if (hits->packed && ((uintptr_t)hits->packed & 15u)) { set_error("packed records must be 16-byte aligned"); return BLU_ERR_INVALID_ARG; }
     if (hipSetDevice(tax->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", tax->device); return BLU_ERR_NO_DEVICE; }
 
-    TaxDev td{tax->d_lin, tax->d_codes, tax->sc, tax->d_lcp8, tax->d_rmq, tax->rmq_nb, tax->d_cutvals, tax->n_cutvals, tax->n_tax, tax->dev_stride, tax->node_base, tax->max_depth};
+    TaxDev td{tax->d_lin, tax->d_codes, tax->d_kthr, tax->sc, tax->d_lcp8, tax->d_rmq, tax->rmq_nb, tax->d_cutvals, tax->n_cutvals, tax->n_tax, tax->dev_stride, tax->node_base, tax->max_depth};
     if (tax->ws_capacity < hits->n_queries || !tax->ws_count) {
         // grows only when a larger table than any before arrives (first call): not graph-capturable
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);

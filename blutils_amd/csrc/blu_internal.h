@@ -42,6 +42,8 @@ struct RankInfo {
 struct TaxDev {
     const uint32_t* lin;     // [n_tax][stride]
     const uint32_t* codes;   // [n_shapes][cstride]
+    const uint32_t* kthr;    // [n_shapes][cstride] per level: smallest milli-percent identity k with fl(k / 1000) >= cutoff (17 bits,
+                             // BLU_KTHR_NEVER if none below it) | (fl(that k / 1000) == cutoff) << 17: `>=` and `>` as integer compares
     uint32_t cstride;        // words per shape row, multiple of 16
     // lcp8[i] = number of leading levels shared by sorted rows i and i+1.  In that order the levels shared by a
     // whole group of rows = min(lcp8[lo .. hi-1]) for the group's smallest/largest pos: a range-minimum query
@@ -60,6 +62,8 @@ struct TaxDev {
 #define BLU_ROW_IV_LEVELS 20u    // levels whose neighbour run lengths sit in the row (words 1..10)
 #define BLU_ROW_RUN_MAX 127u     // a run length byte saturates here
 #define BLU_ROW_NODE_BASE 11u    // first node-id word of a row
+#define BLU_KTHR_BITS 17u
+#define BLU_KTHR_NEVER ((1u << BLU_KTHR_BITS) - 1u)
 #define BLU_PACK_CUT_BITS 12u
 #define BLU_PACK_CODE_BITS 10u
 #define BLU_PACK_CODE_MASK ((1u << BLU_PACK_CODE_BITS) - 1u)
@@ -115,6 +119,7 @@ struct blu_taxonomy {
     std::vector<uint32_t> pos_of;            // caller's tax_row -> sorted position
     double* d_cutvals = nullptr;
     uint32_t* d_codes = nullptr;
+    uint32_t* d_kthr = nullptr;
     uint32_t n_cutvals = 0;
     uint32_t dev_stride = 32;                // words per DEVICE row
     uint32_t node_base = 1;                  // see TaxDev

@@ -1358,9 +1358,23 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 const uint4* codes4 = reinterpret_cast<const uint4*>(codes);
                 const uint32_t b = single ? len_ref : (agree ? minlen - 1 : d - 1);
                 const double ident = pid_f64<PID32>((single | agree) ? r_pid : max_pid);   // the one f64 the cutoff tests need
+                // Milli-percent layouts: `fl(k / 1000) >= c` is monotone in k, so every cutoff c has a smallest k that passes
+                // it (taxonomy.cpp: kthr, 17 bits, + 1 bit "fl(k / 1000) == c", i.e. `>` needs one more) and the level tests
+                // are integer compares of the query's milli-percent identity — no cutoff value is read.  Identities of
+                // 131.071 % and more (not BLAST output) take the f64 tests.
+                uint32_t ident_k = 0;
+                if constexpr (PID32) ident_k = (single | agree) ? r_pid : max_pid;
+                const bool by_k = PID32 && __ballot(ident_k >= BLU_KTHR_NEVER) == 0ull;
+                const uint4* kthr4 = reinterpret_cast<const uint4*>(t.kthr + (uint64_t)(r_hdr >> 8) * t.cstride);
                 // linnaean_ranks.rs:174-212 + build_blast_consensus_identity.rs:67-82
                 uint64_t F = 0, A = 0;
                 uint32_t mar_level = BLU_NONE_U8, nF = 0;
+                uint64_t GE = 0, GT = 0;            // bit j: identity >= / > the cutoff of level j (no dependence between levels)
+                auto level_k = [&](uint32_t j, uint32_t wk) {
+                    const uint32_t kge = wk & BLU_KTHR_NEVER;
+                    GE |= (uint64_t)(ident_k >= kge) << j;
+                    GT |= (uint64_t)(ident_k >= kge + (wk >> BLU_KTHR_BITS)) << j;
+                };
                 auto level = [&](uint32_t j, uint32_t packed) {
                     if (j < len_ref) {
                         const uint32_t cid = packed & ((1u << BLU_PACK_CUT_BITS) - 1u);
@@ -1373,13 +1387,22 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                         }
                     }
                 };
-                uint4 c[4];
+                uint4 c[4], ck[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) c[k] = codes4[k];
+                if (by_k) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ck[k] = kthr4[k];
+                }
                 STAMP_DRAIN
                 STAMP(6)   // (5: run lengths / RMQ) codes arrive
+                if (by_k) {
 #pragma unroll
-                for (int k = 0; k < (BLU_X_SKIP_LEVELS ? 0 : 4); ++k) { level(4 * k, c[k].x); level(4 * k + 1, c[k].y); level(4 * k + 2, c[k].z); level(4 * k + 3, c[k].w); }
+                    for (int k = 0; k < (BLU_X_SKIP_LEVELS ? 0 : 4); ++k) { level_k(4 * k, ck[k].x); level_k(4 * k + 1, ck[k].y); level_k(4 * k + 2, ck[k].z); level_k(4 * k + 3, ck[k].w); }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < (BLU_X_SKIP_LEVELS ? 0 : 4); ++k) { level(4 * k, c[k].x); level(4 * k + 1, c[k].y); level(4 * k + 2, c[k].z); level(4 * k + 3, c[k].w); }
+                }
                 // codes word of level j again (rank codes of the reached / allowed levels): from the registers for the first
                 // 16 levels — going back to memory for them put a third dependent lookup on the task's critical path
                 const uint32_t cw[16] = {c[0].x, c[0].y, c[0].z, c[0].w, c[1].x, c[1].y, c[1].z, c[1].w,
@@ -1392,8 +1415,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     return v;
                 };
                 for (uint32_t k = 4; 4 * k < len_ref; ++k) {   // lineages deeper than 16 levels
-                    const uint4 x = codes4[k];
-                    level(4 * k, x.x); level(4 * k + 1, x.y); level(4 * k + 2, x.z); level(4 * k + 3, x.w);
+                    if (by_k) { const uint4 x = kthr4[k]; level_k(4 * k, x.x); level_k(4 * k + 1, x.y); level_k(4 * k + 2, x.z); level_k(4 * k + 3, x.w); }
+                    else { const uint4 x = codes4[k]; level(4 * k, x.x); level(4 * k + 1, x.y); level(4 * k + 2, x.z); level(4 * k + 3, x.w); }
                 }
                 // node id of level j: words 11..30 of the line are in registers, deeper levels are read from the row
                 const uint32_t nid[20] = {w[2].w, w[3].x, w[3].y, w[3].z, w[3].w, w[4].x, w[4].y, w[4].z, w[4].w, w[5].x,
@@ -1405,6 +1428,24 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     for (uint32_t i = 0; i < 20; ++i) v = (j == i) ? nid[i] : v;
                     return v;
                 };
+                if (by_k) {
+                    const uint64_t lenmask = len_ref >= 64u ? ~0ull : ((1ull << len_ref) - 1ull);
+                    F = GE & lenmask;                                                // filter(identity >= cutoff)
+                    const uint64_t NG = ~GT & lenmask;                               // skip_while(identity > cutoff): first level that stops it
+                    mar_level = NG ? (uint32_t)__builtin_ctzll(NG) : (uint32_t)BLU_NONE_U8;
+                    // the first (b + 1) elements of the filtered list: everything up to the set bit of rank b, if F has that many
+                    A = F;
+                    if ((uint32_t)__builtin_popcountll(F) > b + 1u) {
+                        uint32_t r = b, pos = 0, x = (uint32_t)F;
+                        { const uint32_t cl = (uint32_t)__builtin_popcount((uint32_t)F); const bool up = r >= cl; r -= up ? cl : 0u; x = up ? (uint32_t)(F >> 32) : (uint32_t)F; pos = up ? 32u : 0u; }
+                        { const uint32_t cl = (uint32_t)__builtin_popcount(x & 0xFFFFu); const bool up = r >= cl; r -= up ? cl : 0u; x = up ? x >> 16 : x & 0xFFFFu; pos += up ? 16u : 0u; }
+                        { const uint32_t cl = (uint32_t)__builtin_popcount(x & 0xFFu); const bool up = r >= cl; r -= up ? cl : 0u; x = up ? x >> 8 : x & 0xFFu; pos += up ? 8u : 0u; }
+                        { const uint32_t cl = (uint32_t)__builtin_popcount(x & 0xFu); const bool up = r >= cl; r -= up ? cl : 0u; x = up ? x >> 4 : x & 0xFu; pos += up ? 4u : 0u; }
+                        { const uint32_t cl = (uint32_t)__builtin_popcount(x & 0x3u); const bool up = r >= cl; r -= up ? cl : 0u; x = up ? x >> 2 : x & 0x3u; pos += up ? 2u : 0u; }
+                        pos += (r >= (x & 1u)) ? 1u : 0u;
+                        A = F & ((2ull << pos) - 1ull);
+                    }
+                }
                 if (agree) A = F;                                                  // single hit / single-flag branch (:74-75)
                 if (single) {
                     if (!A) pack_status(ra, rb, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, row0 + r_pos);   // find_single_query_consensus.rs:113-119

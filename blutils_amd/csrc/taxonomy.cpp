@@ -305,6 +305,32 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         dev_codes[k] = cut_id(tax->h_cut[k]) | (rank << BLU_PACK_CUT_BITS) |
                        ((mar == BLU_MAR_NEVER_EQUAL ? BLU_PACK_NEVER : mar) << (BLU_PACK_CUT_BITS + BLU_PACK_CODE_BITS));
     }
+    // per level: the smallest milli-percent identity that passes the cutoff (see TaxDev::kthr).  fl(k / 1000.0) is
+    // increasing in k, so a binary search over k with the very f64 comparison the reference makes is exact.
+    std::vector<uint32_t> dev_kthr(dev_codes.size(), BLU_KTHR_NEVER);
+    {
+        std::map<uint64_t, uint32_t> memo;
+        for (size_t k = 0; k < (size_t)tax->n_shapes * tax->sc; ++k) {
+            const double c = tax->h_cut[k];
+            uint64_t bits;
+            memcpy(&bits, &c, 8);
+            auto it = memo.find(bits);
+            if (it == memo.end()) {
+                uint32_t w = BLU_KTHR_NEVER;
+                if (c == c) {                                   // (a NaN cutoff passes nothing)
+                    uint32_t lo = 0, hi = BLU_KTHR_NEVER;         // smallest k in [0, NEVER) with fl(k / 1000) >= c, else NEVER
+                    while (lo < hi) {
+                        const uint32_t mid = lo + (hi - lo) / 2;
+                        if ((double)mid / 1000.0 >= c) hi = mid; else lo = mid + 1;
+                    }
+                    w = lo;
+                    if (w != BLU_KTHR_NEVER && (double)w / 1000.0 == c) w |= 1u << BLU_KTHR_BITS;
+                }
+                it = memo.emplace(bits, w).first;
+            }
+            dev_kthr[k] = it->second;
+        }
+    }
     if (cutvals.size() >= (1u << BLU_PACK_CUT_BITS)) { delete tax; set_error("more than %u distinct cutoff values", (1u << BLU_PACK_CUT_BITS) - 1); return BLU_ERR_INVALID_ARG; }
     if (cutvals.empty()) cutvals.push_back(0.0);
     tax->n_cutvals = (uint32_t)cutvals.size();
@@ -393,6 +419,8 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_cutvals, b_cut);
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_codes, b_codes);
         if (e == hipSuccess) e = hipMemcpy(tax->d_codes, dev_codes.data(), b_codes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_kthr, b_codes);
+        if (e == hipSuccess) e = hipMemcpy(tax->d_kthr, dev_kthr.data(), b_codes, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_lin, dev_rows.data(), b_lin, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_lcp8, lcp8.data(), lcp8.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_rmq, rmq.data(), rmq.size(), hipMemcpyHostToDevice);
@@ -402,7 +430,7 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
             blu_taxonomy_destroy(tax);
             return BLU_ERR_HIP;
         }
-        tax->device_bytes = b_lin + lcp8.size() + rmq.size() + b_cut + b_codes;
+        tax->device_bytes = b_lin + lcp8.size() + rmq.size() + b_cut + 2 * b_codes;
     }
     *out = tax;
     return BLU_OK;
@@ -417,6 +445,7 @@ void blu_taxonomy_destroy(blu_taxonomy* tax) {
         if (tax->d_rmq) (void)hipFree(tax->d_rmq);
         if (tax->d_cutvals) (void)hipFree(tax->d_cutvals);
         if (tax->d_codes) (void)hipFree(tax->d_codes);
+        if (tax->d_kthr) (void)hipFree(tax->d_kthr);
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
         if (tax->ws_count) (void)hipFree(tax->ws_count);
     }
