@@ -316,18 +316,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // The bit-score stream of a task whose segments are all streamed goes through a per-wave LDS ring, filled by LDS-DMA
 // (buffer_load_dwordx4 ... lds: 1 KiB = 256 rows per wave instruction, no VGPR destination) well ahead of the steps that
 // read it, across task boundaries: a wave no longer pays a memory round trip per step.
-#ifndef BLU_RPL
-#define BLU_RPL 16u              // rows a lane scans in a step of a ring task (8 or 16): a step spans up to 64 BLU_RPL + 255 rows
-#endif
 #ifndef RING_ROWS
-#define RING_ROWS (BLU_RPL * 128u)   // power of two, multiple of 256: the chunks of one step and what is requested ahead
+#define RING_ROWS 2048u          // power of two, multiple of 256: the chunks of one step (up to 1792 rows + alignment slack) / what is requested ahead
 #endif
 #define RING_PAD 32u              // >= rows one lane scans in a step
 #define RING_CHUNKS (RING_ROWS / 256u)
 #define RING_MASK (RING_ROWS - 1u)
-static_assert((RING_ROWS & RING_MASK) == 0 && RING_ROWS >= BLU_RPL * 64u + 512u, "ring size");
-static_assert(BLU_RPL == 8u || BLU_RPL == 16u, "rows per lane");
-#define DESC_SUB_BITS (BLU_RPL == 16u ? 3u : 4u)   // lane descriptor word: top-row mask (BLU_RPL bits) | first row (13 bits) | position / BLU_RPL
+static_assert((RING_ROWS & RING_MASK) == 0 && RING_ROWS >= 2048u, "ring size");
+// A lane of a ring step scans RPL = 16 or 32 consecutive rows (16 for tasks of short segments, 32 otherwise: half as many
+// steps per task).  Lane descriptor in the list: top-row mask | first row (13 bits) | position / RPL (3 bits) — one word with
+// 16 rows per lane (mask in the upper half); with 32 the mask fills the first word and the rest is the second word of the slot.
+#define DESC_SUB_BITS 3u
+#define DESC_WORD0(RPL, mask, row0, sub) ((RPL) == 32u ? (mask) : (((mask) << 16) | ((row0) << DESC_SUB_BITS) | ((sub) / (RPL))))
+#define DESC_WORD1(RPL, row0, sub) (((row0) << DESC_SUB_BITS) | ((sub) / (RPL)))
 static_assert(LIST_CAP >= 128 && LIST_CAP_F64 >= 128, "the list area also stages the 64 records of a task");
 
 template <bool F64>
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         asm volatile("" ::: "memory");              // (keeps these loads in front of the ring requests below: the counted waits rely on it)
         uint32_t fill = 0;   // wave-uniform: entries used in the LDS list
         bool keyed = false;  // wave-uniform: the list of this round holds comparison-ready entries (see gather_list)
+        uint32_t scan_rpl = 16;   // wave-uniform: rows per lane of this round's ring steps (16 or 32: the descriptor format)
         // per-lane (= per-query) results of phase 2a
         // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
         const uint64_t q = q0 + (uint32_t)lane;
@@ -979,7 +981,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     const uint32_t qo = qb + lane_o / LPQ;            // first query that does not fit
                     const bool taken = qi < qo;
                     if (sub == 0) L.meta[qi] = taken ? (idx | (gk << 16)) : META_SLOW;
-                    if (taken && c) L.rec[idx].x = (mask << (32u - RPL)) | (row0 << DESC_SUB_BITS) | (sub / RPL);
+                    if (taken && c) { L.rec[idx].x = DESC_WORD0(RPL, mask, row0, sub); if (RPL == 32u) L.rec[idx].y = DESC_WORD1(RPL, row0, sub); }
                     fill = (uint32_t)rl((int)idx, (int)((qo - qb) * LPQ));   // where the first query left would have started
                     stop_q = qo;
                     wait_vmcnt(0u);
@@ -991,8 +993,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 // a lane with top rows leaves ONE word in the list, at the slot of its first top row: which of its rows are top
                 // rows (RPL bits), its first row relative to the task (13 bits: a ring task has at most 64 x 128 rows) and its
                 // position in the segment / RPL; the slots in between stay 0 and gather_list works the entries out
-                static_assert(RPL == BLU_RPL && SHORT_SEG <= 128u, "descriptor word of a lane");
-                if (c) L.rec[idx].x = (mask << (32u - RPL)) | (row0 << DESC_SUB_BITS) | (sub / RPL);
+                static_assert((RPL == 16u || RPL == 32u) && SHORT_SEG <= 128u, "descriptor word of a lane");
+                if (c) { L.rec[idx].x = DESC_WORD0(RPL, mask, row0, sub); if (RPL == 32u) L.rec[idx].y = DESC_WORD1(RPL, row0, sub); }
             }
         };
         // The list entries of a ring round: lane e of a 64-entry chunk finds the lane descriptor its entry belongs to (the last
@@ -1020,10 +1022,16 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 s = imax(s, __builtin_amdgcn_update_dpp(0, s, 0x143, 0xC, 0xF, false));   // row_bcast:31 into rows 2 and 3
                 s = imax(s, (int)carry);
                 carry = (uint32_t)rl(s, 63);
-                const uint32_t d = L.rec[s].x;
+                const uint32_t d0w = L.rec[s].x;
+                const uint32_t d = scan_rpl == 32u ? L.rec[s].y : d0w;   // (first row, position)
                 // the (idx - s + 1)-th set bit of the mask, counted from its top bit (= the lane's row 0)
-                uint32_t r = idx - (uint32_t)s, x = d >> (32u - BLU_RPL), i = 0;
-                if (BLU_RPL == 16u) {
+                uint32_t r = idx - (uint32_t)s, x = scan_rpl == 32u ? d0w : d0w >> 16, i = 0;
+                if (scan_rpl == 32u) {               // (wave-uniform)
+                    const uint32_t h = x >> 16, ch = (uint32_t)__builtin_popcount(h);
+                    const bool low = r >= ch;
+                    r -= low ? ch : 0u; x = low ? (x & 0xFFFFu) : h; i += low ? 16u : 0u;
+                }
+                {
                     const uint32_t h = x >> 8, ch = (uint32_t)__builtin_popcount(h);
                     const bool low = r >= ch;
                     r -= low ? ch : 0u; x = low ? (x & 0xFFu) : h; i += low ? 8u : 0u;
@@ -1040,7 +1048,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 }
                 i += (r >= (x >> 1)) ? 1u : 0u;
                 const uint32_t row = ((d >> DESC_SUB_BITS) & 0x1FFFu) + i;
-                gpos[u] = (d & ((1u << DESC_SUB_BITS) - 1u)) * BLU_RPL + i;
+                gpos[u] = (d & ((1u << DESC_SUB_BITS) - 1u)) * scan_rpl + i;
                 if (PACKED) g[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, valid ? row * 16u : 0xFFFFFFC0u, 0, GATHER_AUX);
                 else {
                     const uint32_t o4 = valid ? row * 4u : 0xFFFFFFF0u;
@@ -1127,9 +1135,12 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 for (uint32_t u = 0; u * WAVE < CAP; ++u) { const uint32_t i = u * WAVE + (uint32_t)lane; if (i < CAP) L.rec[i].x = 0u; }   // (no entry starts here)
             }
             if (ring_round) {
+                scan_rpl = longest > 32u ? 32u : 16u;                     // rows per lane (measured on C3: 32 -3 %; on 10-hit tables: 16 -2.5 %)
                 uint32_t lpq = 1;
-                while (lpq * BLU_RPL < longest) lpq *= 2;                 // 1 .. 128 / BLU_RPL lanes per query
-                phase1_scan(std::integral_constant<uint32_t, BLU_RPL>(), lpq);
+                while (lpq * scan_rpl < longest) lpq *= 2;                // lanes per query
+                while ((WAVE / lpq) * longest + 256u > RING_ROWS) lpq *= 2;   // and a step's rows (+ alignment slack) inside the ring
+                if (scan_rpl == 32u) phase1_scan(std::integral_constant<uint32_t, 32>(), lpq);
+                else phase1_scan(std::integral_constant<uint32_t, 16>(), lpq);
             }
             else if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>(), false);   // the C3 shape, specialised
             else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u), longest >= (PACKED ? 9u : 25u));   // two-stage steps: measured break-even (packed records: 10 hits -2.5 %, 20 hits -17 %; columns: 20 hits +3 %, 30 hits -6 %)
