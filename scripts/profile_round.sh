@@ -26,5 +26,6 @@ with open(out + "/kernel_stats_blu.csv", "w") as f:
         w.writerow(r)
 print(json.dumps([{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs")} for r in keep], indent=1))
 PY
+[ -n "$TRACE_ONLY" ] && exit 0   # (TRACE_ONLY=1: the bench line and kernel stats again, e.g. after profiles/hbm_traffic.json was published)
 PMC_BENCH_ARGS="$*" scripts/pmc.sh "$out/pmc" "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" > "$out/pmc.log" 2>&1
 tail -3 "$out/pmc.log"
