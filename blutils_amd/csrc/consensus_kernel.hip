@@ -316,6 +316,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // The bit-score stream of a task whose segments are all streamed goes through a per-wave LDS ring, filled by LDS-DMA
 // (buffer_load_dwordx4 ... lds: 1 KiB = 256 rows per wave instruction, no VGPR destination) well ahead of the steps that
 // read it, across task boundaries: a wave no longer pays a memory round trip per step.
+#ifndef BLU_MIXED_RING
+#define BLU_MIXED_RING 0
+#endif
 #ifndef RING_ROWS
 #define RING_ROWS 2048u          // power of two, multiple of 256: the chunks of one step (up to 1792 rows + alignment slack) / what is requested ahead
 #endif
@@ -325,9 +328,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 static_assert((RING_ROWS & RING_MASK) == 0 && RING_ROWS >= 2048u, "ring size");
 // A lane of a ring step scans RPL = 16 or 32 consecutive rows (16 for tasks of short segments, 32 otherwise: half as many
 // steps per task).  Lane descriptor in the list: top-row mask | first row (13 bits) | position / RPL (3 bits) — one word with
-// 16 rows per lane (mask in the upper half); with 32 the mask fills the first word and the rest is the second word of the slot.
+// the mask (top-aligned) is the first word of the list slot, the rest the second (the first row can be far into a task that
+// holds long segments).
 #define DESC_SUB_BITS 3u
-#define DESC_WORD0(RPL, mask, row0, sub) ((RPL) == 32u ? (mask) : (((mask) << 16) | ((row0) << DESC_SUB_BITS) | ((sub) / (RPL))))
 #define DESC_WORD1(RPL, row0, sub) (((row0) << DESC_SUB_BITS) | ((sub) / (RPL)))
 static_assert(LIST_CAP >= 128 && LIST_CAP_F64 >= 128, "the list area also stages the 64 records of a task");
 
@@ -343,6 +346,7 @@ struct WaveLds {
     uint16_t pq[CAP];                       // position of the row in its segment
     uint32_t meta[WAVE + 4];    // first entry | k << 16, or META_SLOW
     uint2 seg[WAVE + 4];        // {first row relative to the task's first row, row count (0 if > MAX_TASK_SEG or outside the span)}
+    uint32_t vx[WAVE + 4];      // first row in the task's ring numbering (whole chunks inside longer segments are left out), [nq] = its end
 };
 
 // waits until at most k of the wave's vector-memory operations are outstanding (k is wave-uniform; s_waitcnt takes an immediate)
@@ -421,8 +425,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(left < 0x80000000ull ? (uint32_t)left : 0x80000000u)), 0x00020000u};
     };
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)L.ring);
-    auto ring_dma = [&](const u32x4 rs, const uint32_t c0, const uint32_t c) {   // one chunk: 64 lanes x 16 bytes, no VGPR destination
-        const uint32_t dst = ring_lds + (c & (RING_CHUNKS - 1u)) * 1024u;
+    auto ring_dma = [&](const u32x4 rs, const uint32_t c0, const uint32_t c, const uint32_t vc) {   // chunk c of the column into the slot of ring chunk vc: 64 lanes x 16 bytes, no VGPR destination
+        const uint32_t dst = ring_lds + (vc & (RING_CHUNKS - 1u)) * 1024u;
         const uint32_t voff = (c - c0) * 1024u + (uint32_t)lane * 16u;
         uint32_t keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen" RING_DMA_MOD " lds\n\ts_mov_b32 m0, %0"
@@ -461,6 +465,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         uint32_t fill = 0;   // wave-uniform: entries used in the LDS list
         bool keyed = false;  // wave-uniform: the list of this round holds comparison-ready entries (see gather_list)
         uint32_t scan_rpl = 16;   // wave-uniform: rows per lane of this round's ring steps (16 or 32: the descriptor format)
+        uint32_t fill_ring = 0;   // wave-uniform: list entries of this round that came from ring steps (lane descriptors until the gather)
         // per-lane (= per-query) results of phase 2a
         // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
         const uint64_t q = q0 + (uint32_t)lane;
@@ -498,16 +503,46 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         // A task whose queries lie back to back in ascending order, none longer than SHORT_SEG rows, can take its
         // bit-scores through the ring (lane i: does query i start where query i - 1 ends?)
         const uint32_t task_rows = (uint32_t)(((uint32_t)lane < nq ? my_end : 0ull) - ((uint32_t)lane < nq ? task_start : 0ull));   // (meaningful in lane nq - 1)
-        bool contiguous;
+        bool contiguous, all_short;
         {
             const uint32_t rel_end = (uint32_t)(my_end - task_start), rel_off = (uint32_t)(my_off - task_start);
             const uint32_t prev_end = (uint32_t)__shfl_up((int)rel_end, 1);
-            const bool ok = in_span && (my_end - my_off) <= SHORT_SEG && (lane == 0 || rel_off == prev_end);
+            const bool ok = in_span && (lane == 0 || rel_off == prev_end);
             contiguous = __ballot((uint32_t)lane < nq && !ok) == 0ull;
+            all_short = __ballot((uint32_t)lane < nq && (my_end - my_off) > SHORT_SEG) == 0ull;
         }
         const uint32_t task_nrows = (uint32_t)rl((int)task_rows, (int)nq - 1);   // rows of the whole task (contiguous tasks)
-        const uint32_t seg_x = (uint32_t)(my_off - task_start);                  // lane i: first row of query i, relative to the task
         const uint64_t vbase = task_start + mis;                                 // v of the task's first row
+        // Segments over SHORT_SEG rows are not read through the ring (long pass / worklist kernel): the whole chunks inside
+        // them are left out of the ring's numbering, so that a task of mixed lengths streams only what its steps read.
+        // Lane i (= query i): chunks left out before it (sk_before), where its own left-out chunks begin in the ring's
+        // numbering and how many are gone after it (ev_*), and its first row in that numbering (seg_x).
+        uint32_t sk_before = 0, ev_v = 0, ev_cum = 0, sk_total = 0;
+        bool ev_on = false;
+        if (BLU_MIXED_RING && contiguous && !all_short) {
+            const uint64_t v0 = vbase + (my_off - task_start), v1 = vbase + (my_end - task_start);
+            const uint32_t c_first = (uint32_t)((v0 + 255u) >> 8), c_past = (uint32_t)(v1 >> 8);
+            const uint32_t kq = ((uint32_t)lane < nq && (my_end - my_off) > SHORT_SEG && c_past > c_first) ? c_past - c_first : 0u;
+            uint32_t incl = kq;
+            incl += (uint32_t)dpp<0x111>((int)incl);
+            incl += (uint32_t)dpp<0x112>((int)incl);
+            incl += (uint32_t)dpp<0x114>((int)incl);
+            incl += (uint32_t)dpp<0x118>((int)incl);
+            const uint32_t t0 = (uint32_t)rl((int)incl, 15), t1 = (uint32_t)rl((int)incl, 31), t2 = (uint32_t)rl((int)incl, 47), t3 = (uint32_t)rl((int)incl, 63);
+            const uint32_t r16 = (uint32_t)lane >> 4;
+            incl += r16 == 0 ? 0u : (r16 == 1 ? t0 : (r16 == 2 ? t0 + t1 : t0 + t1 + t2));
+            sk_before = incl - kq;
+            sk_total = t0 + t1 + t2 + t3;
+            ev_on = kq != 0u;
+            ev_v = c_first - sk_before;
+            ev_cum = incl;
+        }
+        const uint32_t seg_x = (uint32_t)(my_off - task_start) - 256u * sk_before;   // lane i: first row of query i in the ring's numbering, relative to the task
+        L.vx[lane] = seg_x;
+        auto ring_phys = [&](const uint32_t vc) {                               // chunk vc of the ring's numbering -> chunk of the column
+            const uint64_t m = __ballot(ev_on && ev_v <= vc);
+            return m ? vc + (uint32_t)rl((int)ev_cum, 63 - __builtin_clzll(m)) : vc;
+        };
         // ---------------- phase 1: LPQ lanes per query, 4 consecutive rows per lane, 64 / LPQ queries per step ----------------
         // LPQ is chosen per task from its longest segment: 4 lanes (<= 16 rows: blutils' own default is
         // max_target_seqs = 10), 8 (<= 32), 16 (<= 64), 32 (<= 128) or all 64 lanes (<= 256 rows: BLAST's own default
@@ -808,7 +843,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         };
         auto ring_refill = [&]() {                              // request what the ring has room for, in chunk order
             if (ring_head < ring_tail) { ring_head = ring_tail; if (ring_landed < ring_tail) ring_landed = ring_tail; }
-            while (ring_head < ring_end && ring_head - ring_tail < RING_CHUNKS) { ring_dma(rs_ring, ring_c0, ring_head); ++ring_head; }
+            while (ring_head < ring_end && ring_head - ring_tail < RING_CHUNKS) { ring_dma(rs_ring, ring_c0, sk_total ? ring_phys(ring_head) : ring_head, ring_head); ++ring_head; }
         };
         auto phase1_scan = [&](const auto rpl_c, const uint32_t LPQ) {
             constexpr uint32_t RPL = decltype(rpl_c)::value;
@@ -819,7 +854,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 // the rows of this step lie back to back: [first row of query qb, first row of query qb + QPS)
                 const uint32_t r_lo = (uint32_t)rl((int)seg_x, (int)(qb < first_q ? first_q : qb));   // (queries before first_q are done)
                 const uint32_t qn = qb + QPS;
-                const uint32_t r_hi = qn < nq ? (uint32_t)rl((int)seg_x, (int)qn) : task_nrows;
+                const uint32_t r_hi = qn < nq ? (uint32_t)rl((int)seg_x, (int)qn) : task_nrows - 256u * sk_total;
                 STAMP(1)
                 ring_tail = (uint32_t)((vbase + r_lo) >> 8);
                 ring_refill();
@@ -831,8 +866,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 const uint32_t qi = qb + grp;
                 const uint2 sg = L.seg[qi];
                 const int left = (sg.y > short_seg ? 0 : (int)sg.y) - (int)sub;      // rows of the segment from this lane's first row on
-                const uint32_t row0 = sg.x + sub;
-                const uint32_t a = ((uint32_t)vbase + row0) & RING_MASK;
+                const uint32_t row0 = sg.x + sub;                                    // (in the column, relative to the task: what the gather reads)
+                const uint32_t a = ((uint32_t)vbase + L.vx[qi] + sub) & RING_MASK;
                 int b[RPL];
 #pragma unroll
                 for (uint32_t i = 0; i < RPL; ++i) b[i] = (int)L.ring[a + i];
@@ -981,7 +1016,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     const uint32_t qo = qb + lane_o / LPQ;            // first query that does not fit
                     const bool taken = qi < qo;
                     if (sub == 0) L.meta[qi] = taken ? (idx | (gk << 16)) : META_SLOW;
-                    if (taken && c) { L.rec[idx].x = DESC_WORD0(RPL, mask, row0, sub); if (RPL == 32u) L.rec[idx].y = DESC_WORD1(RPL, row0, sub); }
+                    if (taken && c) { L.rec[idx].x = mask << (32u - RPL); L.rec[idx].y = DESC_WORD1(RPL, row0, sub); }
                     fill = (uint32_t)rl((int)idx, (int)((qo - qb) * LPQ));   // where the first query left would have started
                     stop_q = qo;
                     wait_vmcnt(0u);
@@ -994,7 +1029,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 // rows (RPL bits), its first row relative to the task (13 bits: a ring task has at most 64 x 128 rows) and its
                 // position in the segment / RPL; the slots in between stay 0 and gather_list works the entries out
                 static_assert((RPL == 16u || RPL == 32u) && SHORT_SEG <= 128u, "descriptor word of a lane");
-                if (c) { L.rec[idx].x = DESC_WORD0(RPL, mask, row0, sub); if (RPL == 32u) L.rec[idx].y = DESC_WORD1(RPL, row0, sub); }
+                if (c) { L.rec[idx].x = mask << (32u - RPL); L.rec[idx].y = DESC_WORD1(RPL, row0, sub); }
             }
         };
         // The list entries of a ring round: lane e of a 64-entry chunk finds the lane descriptor its entry belongs to (the last
@@ -1009,9 +1044,9 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
                 g[u] = u32x4{0u, 0u, 0u, 0u}; ghi[u] = 0u; gpos[u] = 0u;
-                if ((uint32_t)u * WAVE >= fill) continue;             // (wave-uniform)
+                if ((uint32_t)u * WAVE >= fill_ring) continue;             // (wave-uniform)
                 const uint32_t idx = (uint32_t)u * WAVE + (uint32_t)lane;
-                const bool valid = idx < fill;
+                const bool valid = idx < fill_ring;
                 const uint32_t d0 = L.rec[idx < CAP ? idx : 0u].x;
                 int s = (valid && d0 != 0u) ? (int)idx : 0;           // inclusive max-scan: slot of the descriptor that owns entry idx
                 s = imax(s, dpp<0x111>(s));
@@ -1022,8 +1057,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 s = imax(s, __builtin_amdgcn_update_dpp(0, s, 0x143, 0xC, 0xF, false));   // row_bcast:31 into rows 2 and 3
                 s = imax(s, (int)carry);
                 carry = (uint32_t)rl(s, 63);
-                const uint32_t d0w = L.rec[s].x;
-                const uint32_t d = scan_rpl == 32u ? L.rec[s].y : d0w;   // (first row, position)
+                const uint32_t d0w = L.rec[s].x, d = L.rec[s].y;   // mask | (first row, position)
                 // the (idx - s + 1)-th set bit of the mask, counted from its top bit (= the lane's row 0)
                 uint32_t r = idx - (uint32_t)s, x = scan_rpl == 32u ? d0w : d0w >> 16, i = 0;
                 if (scan_rpl == 32u) {               // (wave-uniform)
@@ -1047,7 +1081,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     r -= low ? ch : 0u; x = low ? (x & 0x3u) : h; i += low ? 2u : 0u;
                 }
                 i += (r >= (x >> 1)) ? 1u : 0u;
-                const uint32_t row = ((d >> DESC_SUB_BITS) & 0x1FFFu) + i;
+                const uint32_t row = (d >> DESC_SUB_BITS) + i;
                 gpos[u] = (d & ((1u << DESC_SUB_BITS) - 1u)) * scan_rpl + i;
                 if (PACKED) g[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, valid ? row * 16u : 0xFFFFFFC0u, 0, GATHER_AUX);
                 else {
@@ -1070,13 +1104,13 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             bool ovf = false;
             if (PID32) {
 #pragma unroll
-                for (int u = 0; u < NG; ++u) ovf |= ((uint32_t)u * WAVE + (uint32_t)lane < fill) && g[u].y >= (1u << KEY_PID_BITS);
+                for (int u = 0; u < NG; ++u) ovf |= ((uint32_t)u * WAVE + (uint32_t)lane < fill_ring) && g[u].y >= (1u << KEY_PID_BITS);
             }
-            keyed = PID32 && __ballot(ovf) == 0ull;
+            keyed = PID32 && __ballot(ovf) == 0ull && fill == fill_ring;   // (entries appended by the long pass are plain records)
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
                 const uint32_t idx = (uint32_t)u * WAVE + (uint32_t)lane;
-                if (idx < fill) {
+                if (idx < fill_ring) {
                     if (keyed) {
                         const uint32_t len = umin(g[u].x >> BLU_ROW_BITS, t.max_depth);
                         L.rec[idx] = make_uint4((g[u].x & ROW_MASK) | (len << BLU_ROW_BITS), (len << KEY_PID_BITS) | g[u].y, g[u].z ^ 0x80000000u, g[u].w);
@@ -1095,7 +1129,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         if (contiguous) {                                            // this task's chunks; what the task before requested ahead stays
             ring_c0 = (uint32_t)(vbase >> 8);
             rs_ring = ring_desc(ring_c0);
-            ring_end = task_nrows ? (uint32_t)((vbase + task_nrows - 1u) >> 8) + 1u : ring_c0;
+            ring_end = task_nrows ? (uint32_t)((vbase + task_nrows - 1u) >> 8) + 1u - sk_total : ring_c0;
             if (pref_task != task) ring_head = ring_landed = ring_c0;
             ring_tail = ring_c0;
         }
@@ -1129,16 +1163,28 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             }
 #endif
             const uint32_t longest = wave_max_u32(rows > short_seg ? 0u : rows);   // longest streamed segment of the task
-            ring_round = contiguous && longest != 0u && __ballot(rows > short_seg) == 0ull;
+            // (BLU_MIXED_RING: tasks that also hold longer segments through the ring, their whole chunks left out — written in
+            // round 2, gains 4 % on C5 as it stands and still gives two wrong records on the scaled C5 test: off)
+            ring_round = contiguous && longest != 0u && (all_short ? __ballot(rows > short_seg) == 0ull : (bool)BLU_MIXED_RING);
+            uint32_t lpq = 1;
+            if (ring_round) {
+                scan_rpl = longest > 32u ? 32u : 16u;                     // rows per lane (measured on C3: 32 -3 %; on 10-hit tables: 16 -2.5 %)
+                while (lpq * scan_rpl < longest) lpq *= 2;                // lanes per query
+                while ((WAVE / lpq) * longest + 256u > RING_ROWS) lpq *= 2;   // and a step's rows (+ alignment slack) inside the ring
+                if (!all_short) {
+                    // a task of mixed lengths: the partial chunks of the longer segments between a step's queries count too
+                    const uint32_t qps = WAVE / lpq, qe = (uint32_t)lane + qps < nq ? (uint32_t)lane + qps : nq;
+                    if ((uint32_t)lane == 0) L.vx[nq] = task_nrows - 256u * sk_total;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const uint32_t span = L.vx[qe] - seg_x;
+                    ring_round = __ballot((uint32_t)lane < nq && ((uint32_t)lane & (qps - 1u)) == 0u && span + 256u > RING_ROWS) == 0ull;
+                }
+            }
             if (ring_round) {
 #pragma unroll
                 for (uint32_t u = 0; u * WAVE < CAP; ++u) { const uint32_t i = u * WAVE + (uint32_t)lane; if (i < CAP) L.rec[i].x = 0u; }   // (no entry starts here)
-            }
-            if (ring_round) {
-                scan_rpl = longest > 32u ? 32u : 16u;                     // rows per lane (measured on C3: 32 -3 %; on 10-hit tables: 16 -2.5 %)
-                uint32_t lpq = 1;
-                while (lpq * scan_rpl < longest) lpq *= 2;                // lanes per query
-                while ((WAVE / lpq) * longest + 256u > RING_ROWS) lpq *= 2;   // and a step's rows (+ alignment slack) inside the ring
                 if (scan_rpl == 32u) phase1_scan(std::integral_constant<uint32_t, 32>(), lpq);
                 else phase1_scan(std::integral_constant<uint32_t, 16>(), lpq);
             }
@@ -1146,6 +1192,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u), longest >= (PACKED ? 9u : 25u));   // two-stage steps: measured break-even (packed records: 10 hits -2.5 %, 20 hits -17 %; columns: 20 hits +3 %, 30 hits -6 %)
             // queries phase 1 did not get to (the list filled up): marked for the next round, long ones included
             if (stop_q < WAVE && rows != 0u && ((uint32_t)lane >= stop_q || rows > short_seg)) L.meta[lane] = META_SLOW;
+            fill_ring = ring_round ? fill : 0u;                     // (what follows appends whole records, not lane descriptors)
             const uint64_t long_mask = __ballot(rows > short_seg);
             if (long_mask && stop_q == WAVE) phase1_long(long_mask);   // after the streamed pass: it overwrites their (empty) list heads
         }
@@ -1183,7 +1230,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         auto prefetch_next = [&]() {
             if (nxt_lim > nxt_c0) {
                 const auto rsn = ring_desc(nxt_c0);
-                for (uint32_t c = nxt_c0; c < nxt_lim; ++c) ring_dma(rsn, nxt_c0, c);
+                for (uint32_t c = nxt_c0; c < nxt_lim; ++c) ring_dma(rsn, nxt_c0, c, c);
                 ring_head = nxt_lim; ring_landed = nxt_c0; ring_tail = nxt_c0;
                 pref_task = next_task;
             }
