@@ -319,6 +319,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef BLU_MIXED_RING
 #define BLU_MIXED_RING 0
 #endif
+#ifndef BLU_MIXED_MAX_LPQ
+#define BLU_MIXED_MAX_LPQ 16u    // most lanes per query a task of mixed lengths may take to make its steps fit the ring
+#endif
 #ifndef RING_ROWS
 #define RING_ROWS 2048u          // power of two, multiple of 256: the chunks of one step (up to 1792 rows + alignment slack) / what is requested ahead
 #endif
@@ -850,6 +853,12 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             static_assert(RPL <= RING_PAD && RPL <= 32u, "rows per lane");
             const uint32_t QPS = WAVE / LPQ;
             const uint32_t grp = (uint32_t)lane / LPQ, sub = ((uint32_t)lane & (LPQ - 1u)) * RPL, row16 = (uint32_t)lane >> 4;
+            {
+                // A round that starts behind what the ring still holds (a query that an earlier round left to the long pass
+                // and this round's width takes into the steps) starts the ring over at its first row.
+                const uint32_t cs = (uint32_t)((vbase + (uint32_t)rl((int)seg_x, (int)first_q)) >> 8);
+                if (cs < ring_tail) { wait_vmcnt(0u); ring_head = ring_landed = ring_tail = cs; }
+            }
             for (uint32_t qb = first_q / QPS * QPS; qb < nq; qb += QPS) {
                 // the rows of this step lie back to back: [first row of query qb, first row of query qb + QPS)
                 const uint32_t r_lo = (uint32_t)rl((int)seg_x, (int)(qb < first_q ? first_q : qb));   // (queries before first_q are done)
@@ -1163,8 +1172,8 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             }
 #endif
             const uint32_t longest = wave_max_u32(rows > short_seg ? 0u : rows);   // longest streamed segment of the task
-            // (BLU_MIXED_RING: tasks that also hold longer segments through the ring, their whole chunks left out — written in
-            // round 2, gains 4 % on C5 as it stands and still gives two wrong records on the scaled C5 test: off)
+            // (BLU_MIXED_RING: tasks that also hold longer segments through the ring, their whole chunks left out — correct
+            // (full GPU suite green with it) but no gain on C5, whose steps shrink to a few queries each: off)
             ring_round = contiguous && longest != 0u && (all_short ? __ballot(rows > short_seg) == 0ull : (bool)BLU_MIXED_RING);
             uint32_t lpq = 1;
             if (ring_round) {
@@ -1172,14 +1181,19 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                 while (lpq * scan_rpl < longest) lpq *= 2;                // lanes per query
                 while ((WAVE / lpq) * longest + 256u > RING_ROWS) lpq *= 2;   // and a step's rows (+ alignment slack) inside the ring
                 if (!all_short) {
-                    // a task of mixed lengths: the partial chunks of the longer segments between a step's queries count too
-                    const uint32_t qps = WAVE / lpq, qe = (uint32_t)lane + qps < nq ? (uint32_t)lane + qps : nq;
+                    // a task of mixed lengths: the partial chunks of the longer segments between a step's queries count too —
+                    // fewer queries per step (more lanes per query) until every step's rows fit the ring, or no ring
                     if ((uint32_t)lane == 0) L.vx[nq] = task_nrows - 256u * sk_total;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const uint32_t span = L.vx[qe] - seg_x;
-                    ring_round = __ballot((uint32_t)lane < nq && ((uint32_t)lane & (qps - 1u)) == 0u && span + 256u > RING_ROWS) == 0ull;
+                    for (;;) {
+                        const uint32_t qps = WAVE / lpq, qe = (uint32_t)lane + qps < nq ? (uint32_t)lane + qps : nq;
+                        const uint32_t span = L.vx[qe] - seg_x;
+                        if (__ballot((uint32_t)lane < nq && ((uint32_t)lane & (qps - 1u)) == 0u && span + 256u > RING_ROWS) == 0ull) break;
+                        if (lpq >= BLU_MIXED_MAX_LPQ) { ring_round = false; break; }
+                        lpq *= 2;
+                    }
                 }
             }
             if (ring_round) {
