@@ -20,6 +20,7 @@ for step in "$@"; do
     tests)      run tests 1100 python -m pytest tests -m gpu -x -q ;;
     tests_fast) run tests_fast 600 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_fullsize.py ;;
     bench)      run bench 300 python bench.py ;;
+    smoke)      run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench_q)    run bench_q 200 python bench.py --no-cpu-baseline --cpu-sample 100000 ;;
     dist)       BLU_BENCH_FORCE_DIST=1 run dist 300 python bench.py --steps 10 --no-cpu-baseline --cpu-sample 100000 ;;
     zymo)       run zymo 200 python bench.py --top-group zymo --no-cpu-baseline --cpu-sample 100000 ;;
