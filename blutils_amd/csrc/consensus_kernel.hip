@@ -5,26 +5,33 @@
 // build_blast_consensus_identity.rs:9-105 (restated in SURVEY §3.3).
 //
 // Kernel A  blu_consensus_stream_kernel — segments of up to 512 hits.
-//   A wave task is 64 consecutive queries; the waves of a block take consecutive tasks.
-//   phase 1 (lane = 4 consecutive hit rows): segments of up to 128 rows in steps of 64 lanes with 4 .. 32 lanes per
-//     query (chosen per task); segments of 129 .. 512 rows in a long pass of two 256-row slots per step.  A step
-//     loads the bit-scores (16-byte buffer loads), finds the top score by a DPP reduction over the query's lanes and
-//     ranks the top rows by a DPP scan; the other four values of a hit (taxonomy row, perc_identity, align_length,
-//     accession rank — 16-byte side records in the packed layout, four columns otherwise) are then loaded for the
-//     top rows only, and compacted in file order into a per-wave LDS list.  (Tasks of very short segments load
-//     everything at once.)  The row id carries the lineage length: no taxonomy lookup here.
-//   phase 2a (lane = query, LDS only): parse errors, reference row by the stable-sort
-//     rule, shortest lineage, group-max pident, span [lo, hi] in sorted lineage order.
-//   phase 2c (lane = query): one 128-byte line of the reference row gives, per level,
-//     how far the neighbouring rows share it (-> the first disagreeing level of the
-//     span; a range minimum over the adjacent-row LCP array for wide spans) and the
-//     node ids; per-level cutoff ids (values in LDS) and rank codes come from the
-//     table row of the lineage's shape; cutoff tests; record.
+//   A wave task is 64 consecutive queries; the waves stride over the tasks on their own (no block-level barrier in the
+//   loop); the offsets of a task are requested one task ahead.
+//   phase 1, ring tasks (queries back to back, none over 128 rows): the bit-score column streams through a per-wave
+//     LDS ring filled by LDS-DMA (256-row chunks, requested as far ahead as the ring has room — across task boundaries —
+//     and waited for with counted s_waitcnt vmcnt); a lane scans 16 or 32 consecutive rows of its query out of the ring,
+//     the maximum and the top-row counts cross lanes by DPP, and a lane with top rows leaves one descriptor in the list;
+//     the list entries are worked out of the descriptors one entry per lane and the 16 other bytes of those rows
+//     gathered, every load in flight at once.  A step whose top rows would not fit an empty list (whole groups tied)
+//     is reduced by the lanes that scanned it (dense step), without the list.
+//   phase 1, other tasks (lane = 4 consecutive hit rows): segments of up to 128 rows in steps of 64 lanes with 4 .. 32
+//     lanes per query (chosen per task); segments of 129 .. 512 rows in a long pass of two 256-row slots per step.  A
+//     step loads the bit-scores (16-byte buffer loads), finds the top score by a DPP reduction over the query's lanes
+//     and ranks the top rows by a DPP scan; the other four values of a hit (taxonomy row, perc_identity, align_length,
+//     accession rank — 16-byte side records in the packed layout, four columns otherwise) are then loaded for the top
+//     rows only, and compacted in file order into the per-wave LDS list.
+//   The row id carries the lineage length: no taxonomy lookup in phase 1.
+//   phase 2a (lane = query, LDS only): parse errors, reference row by the stable-sort rule, shortest lineage, group-max
+//     pident, span [lo, hi] in sorted lineage order — one uniform loop over the list.
+//   phase 2c (lane = query): one 128-byte line of the reference row gives, per level, how far the neighbouring rows
+//     share it (-> the first disagreeing level of the span, four levels per subtraction; a range minimum over the
+//     adjacent-row LCP array for wide spans, requested together with the row) and the node ids; rank codes and cutoffs
+//     come from the table rows of the lineage's shape — in the milli-percent layouts the cutoff tests are integer
+//     compares against per-level thresholds; record.
 //   Records are staged in LDS and leave as one write-through 2 KiB run per wave task.
-//   Queries with more than 512 hits, or whose top group does not fit the LDS
-//   list, are appended to a worklist.
-// Kernel B  blu_consensus_long_kernel — worklist queries, one wave per query,
-//   chunked passes over the segment (any length), wave-parallel finalisation.
+//   Queries with more than 512 hits, or whose top group does not fit the LDS list, are appended to a worklist.
+// Kernel B  blu_consensus_long_kernel — worklist queries, one wave per query: chunked passes over the bit-scores (any
+//   length), top rows collected in LDS slots and their side records gathered one row per lane, wave-parallel finalisation.
 //
 // Integer/compare work only: no MFMA.  HBM-bound: every bit-score is read (4 B/hit), the other 16 B/hit for top rows
 // only, one reference-row line and one 32-byte record per query.
