@@ -7,6 +7,7 @@
 #include <memory>
 #include <utility>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "blu_consensus.h"
@@ -73,7 +74,7 @@ struct DeviceHits {
     uint64_t n_hits = 0, n_queries = 0;
     int32_t* bitscore = nullptr;
     int32_t* align_len = nullptr;
-    uint32_t* tax_desc_row = nullptr;   // rewritten in place to engine row ids by device_run_consensus
+    uint32_t* tax_desc_row = nullptr;   // desc row indices (the engine's row ids are derived in device_run_consensus)
     uint32_t* acc_rank = nullptr;
     double* pident = nullptr;
     unsigned long long* seg_off = nullptr;   // [n_queries + 1]
@@ -90,7 +91,35 @@ struct HitTable {
     Column<double> pident;
     std::vector<std::string> accessions;         // sorted (String::cmp)
     uint64_t unmatched = 0;
+    uint64_t n_hits = 0;                         // rows of the table (the host columns may be absent, see below)
+    bool host_columns = true;                    // false: the GPU ingest was asked to leave the columns on the device only
     std::unique_ptr<DeviceHits> dev;             // set by the GPU ingest
+    // The GPU ingest returns as soon as the device columns are complete; query_names and accessions (already sized) are
+    // still being filled by this thread from the distinct strings the device sent back.  wait_strings() before either
+    // is read.
+    std::thread strings_thread;
+    void wait_strings() { if (strings_thread.joinable()) strings_thread.join(); }
+    void clear() {
+        wait_strings();
+        query_names.clear(); accessions.clear();
+        seg_off = {}; bitscore = {}; align_len = {}; tax_desc_row = {}; acc_rank = {}; pident = {};
+        unmatched = n_hits = 0; host_columns = true;
+        dev.reset();
+    }
+    HitTable() = default;
+    HitTable(const HitTable&) = delete;
+    HitTable& operator=(const HitTable&) = delete;
+    ~HitTable() { wait_strings(); }
+};
+
+// What the writer reads of the hit table: the rows of every rendered query's top-score group, in file order
+// (find_single_query_consensus.rs:51-64 — the top group is all the reference ever parses).  On the GPU path it is
+// compacted on the device and is the only part of the table that crosses PCIe on the way back.
+struct TopRow { uint32_t row, desc_row, acc_rank; int32_t align_len; double pident; };   // 24 bytes
+struct TopTable {
+    Column<uint64_t> off;        // [n_queries + 1]; empty group: query not rendered (status >= 2)
+    Column<TopRow> rows;
+    Column<int32_t> score;       // [n_queries] the group's bit-score
 };
 
 
@@ -99,12 +128,18 @@ struct HitTable {
 // outfmt-6 text -> grouped SoA columns on the GPU (ingest_gpu.hip).  Same result as the CPU ingest, bit for bit, for
 // files in the plain BLAST form (no quotes, no empty lines, numbers of <= 15 significant digits); anything else returns
 // BLU_INGEST_FALLBACK with the reason in *why and the caller parses on the CPU.
-int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int device, HitTable& ht, std::string* why);
+// host_columns = false: the grouped columns stay on the device only (ht.dev) — download_columns() fetches them later
+// if they turn out to be needed.
+// fd: the table, open for reading (the text is read with pread straight into pinned staging buffers).
+int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool host_columns, HitTable& ht, std::string* why);
+int download_columns(HitTable& ht);
 
 // The engine on the columns the GPU ingest left on the device: taxonomy rows -> engine row ids (fwd = blu_taxonomy_row_map's
 // forward table), perc_identity as milli-percent when every value is exactly k/1000 (checked on the device), one
-// blu_consensus_run with device pointers, records copied to `out` (host).  Frees the device columns.
-int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_t* fwd, uint64_t n_tax, int strategy, blu_result* out);
+// blu_consensus_run with device pointers, records copied to `out` (host) and the top-score rows of the rendered
+// queries compacted into `top`.  The device columns are left as they were.
+int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_t* fwd, uint64_t n_tax, int strategy, blu_result* out,
+                         TopTable* top);
 
 }  // namespace blu
 #endif

@@ -21,9 +21,11 @@
 // written here.  HBM-bound byte work: no MFMA.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -317,6 +319,20 @@ __global__ void gather_key16(const unsigned long long* __restrict__ pos, uint32_
 }
 
 // ---- 5. grouping ---------------------------------------------------------------------------------------------------
+// the distinct strings themselves, packed back to back: lengths -> (exclusive scan) -> bytes
+__global__ void pos_lengths(const unsigned long long* __restrict__ pos, uint32_t n, unsigned long long* __restrict__ len) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) len[i] = i < n ? pos[i] >> 44 : 0ull;
+}
+__global__ void gather_bytes(const unsigned long long* __restrict__ pos, uint32_t n, const unsigned char* __restrict__ text,
+                             const unsigned long long* __restrict__ off, unsigned char* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t src = pos[i] & ((1ull << 44) - 1);
+    const uint32_t len = (uint32_t)(pos[i] >> 44);
+    unsigned char* d = out + off[i];
+    for (uint32_t k = 0; k < len; ++k) d[k] = text[src + k];
+}
 __global__ void check_grouped(const uint32_t* __restrict__ qid, uint32_t n, uint32_t* __restrict__ unsorted) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > 0 && i < n && qid[i] < qid[i - 1]) *unsorted = 1u;
@@ -377,7 +393,63 @@ struct DeviceArena {
     ~DeviceArena() { for (void* p : ptrs) (void)hipFree(p); }
 };
 
-int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int device, HitTable& ht, std::string* why) {
+// The text goes page cache -> pinned staging -> HBM without ever being mapped into the process: a few reader threads,
+// each with two pinned slots and a stream of its own, pread() a piece while the previous one is on the wire (6.7 GB in
+// 0.22 s including the allocation of the device buffer).  Mapping the file and handing it to one hipMemcpy moves the
+// bytes as fast but leaves 6.7 GB of populated page table behind: unmapping it took 0.08 s and held up every
+// allocation made meanwhile; synchronous copies out of the same pinned slots were 10 % slower.
+static int upload_file(int fd, size_t size, unsigned char* d_text, int device, std::string* err) {
+    unsigned nt = 6;
+    if (const char* env = getenv("BLU_UPLOAD_THREADS")) nt = (unsigned)atoi(env);
+    const size_t piece = 8u << 20, n_pieces = (size + piece - 1) / piece;
+    nt = std::max(1u, std::min<unsigned>(nt, (unsigned)std::max<size_t>(n_pieces, 1)));
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    std::vector<std::string> errs(nt);
+    auto work = [&](unsigned t) {
+        char* slots = nullptr;
+        hipStream_t st = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool busy[2] = {false, false};
+        auto fail = [&](const char* what, hipError_t e) { errs[t] = std::string(what) + ": " + (e == hipSuccess ? strerror(errno) : hipGetErrorString(e)); failed = 1; };
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&slots, 2 * piece, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+        if (e != hipSuccess) fail("staging set-up", e);
+        unsigned turn = 0;
+        while (!failed.load(std::memory_order_relaxed)) {
+            const size_t k = next.fetch_add(1);
+            if (k >= n_pieces) break;
+            const unsigned sl = turn++ & 1;
+            if (busy[sl] && (e = hipEventSynchronize(ev[sl])) != hipSuccess) { fail("hipEventSynchronize", e); break; }
+            const size_t off = k * piece, len = std::min(piece, size - off);
+            size_t got = 0;
+            while (got < len) {
+                const ssize_t r = pread(fd, slots + sl * piece + got, len - got, (off_t)(off + got));
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0) { fail("pread", hipSuccess); break; }
+                got += (size_t)r;
+            }
+            if (got < len) break;
+            if ((e = hipMemcpyAsync(d_text + off, slots + sl * piece, len, hipMemcpyHostToDevice, st)) != hipSuccess) { fail("hipMemcpyAsync", e); break; }
+            if ((e = hipEventRecord(ev[sl], st)) != hipSuccess) { fail("hipEventRecord", e); break; }
+            busy[sl] = true;
+        }
+        if (st) { e = hipStreamSynchronize(st); if (e != hipSuccess && !failed) fail("hipStreamSynchronize", e); }
+        for (int k = 0; k < 2; ++k) if (ev[k]) (void)hipEventDestroy(ev[k]);
+        if (st) (void)hipStreamDestroy(st);
+        if (slots) (void)hipHostFree(slots);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    if (failed) { for (auto& m : errs) if (!m.empty()) { *err = m; break; } return BLU_ERR_IO; }
+    return BLU_OK;
+}
+
+int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool host_columns, HitTable& ht, std::string* why) {
     int rc = BLU_OK;
     DeviceArena mem;
     const bool oom_fallback = true;
@@ -416,6 +488,11 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
     Slot *d_qtab = nullptr, *d_atab = nullptr;
     unsigned long long* d_seg = nullptr;
     uint32_t h_flags = 0, n_rows = 0, n_queries = 0, n_acc = 0;
+    // the distinct query / accession strings packed back to back (bytes + n + 1 offsets) and the accessions' byte order:
+    // what the strings thread started at the end needs
+    std::vector<char> q_bytes, a_bytes;
+    std::vector<unsigned long long> q_off, a_off;
+    std::vector<uint32_t> order;
     uint64_t n_tiles = (size + TILE_BYTES - 1) / TILE_BYTES;
     auto need_tmp = [&](size_t bytes) -> hipError_t {
         if (bytes <= tmp_bytes) return hipSuccess;
@@ -426,11 +503,40 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         return e;
     };
     auto grid = [](uint64_t n, uint32_t b = 256) { return dim3((unsigned)((n + b - 1) / b)); };
+    // distinct strings at d_pos[0 .. n) of the device text -> host
+    auto download_strings = [&](const unsigned long long* d_pos, uint32_t n, std::vector<char>& bytes, std::vector<unsigned long long>& off) -> int {
+        int rc = BLU_OK;
+        unsigned long long *d_len = nullptr, *d_off = nullptr;
+        unsigned char* d_out = nullptr;
+        off.assign((size_t)n + 1, 0);
+        HIPCHK(mem.alloc((void**)&d_len, ((size_t)n + 1) * 8));
+        HIPCHK(mem.alloc((void**)&d_off, ((size_t)n + 1) * 8));
+        hipLaunchKernelGGL(pos_lengths, dim3((n + 256) / 256), dim3(256), 0, 0, d_pos, n, d_len);
+        {
+            size_t b = 0;
+            HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_len, d_off, (int)(n + 1)));
+            HIPCHK(need_tmp(b));
+            HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, b, d_len, d_off, (int)(n + 1)));
+        }
+        HIPCHK(hipMemcpy(off.data(), d_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+        bytes.resize(off[n]);
+        HIPCHK(mem.alloc((void**)&d_out, std::max<size_t>(off[n], 16)));
+        if (n) hipLaunchKernelGGL(gather_bytes, dim3((n + 255) / 256), dim3(256), 0, 0, d_pos, n, d_text, d_off, d_out);
+        HIPCHK(hipMemcpy(bytes.data(), d_out, off[n], hipMemcpyDeviceToHost));
+    done:
+        mem.free(d_len); mem.free(d_off); mem.free(d_out);
+        return rc;
+    };
 
     // ---- upload + line index
+    lap("device start-up");
     HIPCHK(mem.alloc((void**)&d_text, size + 64));
     HIPCHK(hipMemset(d_text + (size & ~15ull), 0, 64 + (size & 15)));
-    HIPCHK(hipMemcpy(d_text, text, size, hipMemcpyHostToDevice));
+    {
+        std::string io;
+        rc = upload_file(fd, size, d_text, device, &io);
+        if (rc != BLU_OK) { set_error("GPU ingest: reading the table failed: %s", io.c_str()); goto done; }
+    }
     lap("upload text");
     HIPCHK(mem.alloc((void**)&d_tile, (n_tiles + 1) * 4));
     HIPCHK(mem.alloc((void**)&d_tile_base, (n_tiles + 1) * 4));
@@ -449,7 +555,9 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
     {
         uint32_t n_newlines = 0;
         HIPCHK(hipMemcpy(&n_newlines, d_tile_base + n_tiles, 4, hipMemcpyDeviceToHost));
-        const bool open_tail = text[size - 1] != '\n';
+        char last = 0;
+        if (pread(fd, &last, 1, (off_t)(size - 1)) != 1) { set_error("GPU ingest: reading the table failed"); rc = BLU_ERR_IO; goto done; }
+        const bool open_tail = last != '\n';
         const uint64_t rows64 = (uint64_t)n_newlines + (open_tail ? 1 : 0);
         if (rows64 >= 0x7FFFFFF0ull) { rc = fallback("2^31 rows or more"); goto done; }
         n_rows = (uint32_t)rows64;
@@ -490,6 +598,7 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         HIPCHK(hipMemcpy(&n_queries, d_counter, 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
         if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
+        lap("  query: insert");
         HIPCHK(mem.alloc((void**)&d_list_row, (size_t)n_queries * 4)); HIPCHK(mem.alloc((void**)&d_list_slot, (size_t)n_queries * 4));
         HIPCHK(mem.alloc((void**)&d_list_row2, (size_t)n_queries * 4)); HIPCHK(mem.alloc((void**)&d_list_slot2, (size_t)n_queries * 4));
         HIPCHK(hipMemset(d_counter, 0, 4));
@@ -503,25 +612,13 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         hipLaunchKernelGGL(dict_lookup, grid(n_rows), dim3(256), 0, 0, d_qh, d_qpos, n_rows, d_qtab, cap - 1, d_text, d_qpos, d_qid, d_flags);
         HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
         if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
+        lap("  query: ids of the rows");
         // query names: the text of each query's first row, in id order
         HIPCHK(mem.alloc((void**)&d_poslist, (size_t)n_queries * 8));
         hipLaunchKernelGGL(gather_pos, grid(n_queries), dim3(256), 0, 0, d_qpos, d_list_row2, n_queries, d_poslist);
-        std::vector<unsigned long long> qp(n_queries);
-        HIPCHK(hipMemcpy(qp.data(), d_poslist, (size_t)n_queries * 8, hipMemcpyDeviceToHost));
-        ht.query_names.resize(n_queries);
-        {
-            unsigned nt = std::thread::hardware_concurrency();
-            if (const char* env = getenv("BLU_INGEST_THREADS")) nt = (unsigned)atoi(env);
-            nt = std::max(1u, std::min(nt, 32u));
-            if (n_queries < 65536) nt = 1;
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t < nt; ++t)
-                pool.emplace_back([&, t]() {
-                    for (size_t q = (size_t)n_queries * t / nt; q < (size_t)n_queries * (t + 1) / nt; ++q)
-                        ht.query_names[q].assign(text + (qp[q] & ((1ull << 44) - 1)), (size_t)(qp[q] >> 44));
-                });
-            for (auto& th : pool) th.join();
-        }
+        rc = download_strings(d_poslist, n_queries, q_bytes, q_off);
+        if (rc != BLU_OK) goto done;
+        lap("  query: names");
         mem.free(d_poslist); d_poslist = nullptr;
         mem.free(d_list_row); mem.free(d_list_slot); mem.free(d_list_row2); mem.free(d_list_slot2);
         d_list_row = d_list_slot = d_list_row2 = d_list_slot2 = nullptr;
@@ -536,6 +633,7 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         uint64_t cap = pow2_at_least(std::min<uint64_t>((uint64_t)n_rows * 2 + 16, 1ull << 22));
         for (;;) {
             HIPCHK(mem.alloc((void**)&d_atab, cap * sizeof(Slot)));
+            lap("  acc: table allocation");
             hipLaunchKernelGGL(dict_init, grid(cap), dim3(256), 0, 0, d_atab, cap);
             HIPCHK(hipMemset(d_counter, 0, 4));
             HIPCHK(hipMemset(d_flags, 0, 4));
@@ -554,8 +652,8 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         hipLaunchKernelGGL(dict_finalize, grid(cap), dim3(256), 0, 0, d_atab, cap, d_text, d_apos, d_list_row, d_list_slot, d_counter);
         HIPCHK(mem.alloc((void**)&d_poslist, (size_t)n_acc * 8));
         hipLaunchKernelGGL(gather_pos, grid(n_acc), dim3(256), 0, 0, d_apos, d_list_row, n_acc, d_poslist);
-        std::vector<unsigned long long> ap(n_acc);
-        HIPCHK(hipMemcpy(ap.data(), d_poslist, (size_t)n_acc * 8, hipMemcpyDeviceToHost));
+        rc = download_strings(d_poslist, n_acc, a_bytes, a_off);
+        if (rc != BLU_OK) goto done;
         lap("  acc: distinct to host");
         // byte order of the distinct accessions (String::cmp), on the host: only the distinct strings are touched, and
         // mostly not even those — the GPU hands over their first 16 bytes as two big-endian integers; the text is read
@@ -574,13 +672,13 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
             mem.free(d_k1);
             HIPCHK(e2);
         }
-        std::vector<uint32_t> order(n_acc);
+        order.resize(n_acc);
         for (uint32_t k = 0; k < n_acc; ++k) order[k] = k;
-        auto view = [&](uint32_t k) { return std::string_view(text + (ap[k] & ((1ull << 44) - 1)), (size_t)(ap[k] >> 44)); };
+        auto view = [&](uint32_t k) { return std::string_view(a_bytes.data() + a_off[k], (size_t)(a_off[k + 1] - a_off[k])); };
         auto less = [&](uint32_t a, uint32_t b) {
             if (k0[a] != k0[b]) return k0[a] < k0[b];
             if (k1[a] != k1[b]) return k1[a] < k1[b];
-            const size_t la = (size_t)(ap[a] >> 44), lb = (size_t)(ap[b] >> 44);
+            const size_t la = (size_t)(a_off[a + 1] - a_off[a]), lb = (size_t)(a_off[b + 1] - a_off[b]);
             if (la <= 16 && lb <= 16) return la < lb;          // equal padded prefixes: the shorter string sorts first
             return view(a) < view(b);
         };
@@ -600,9 +698,7 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         }
         lap("  acc: host sort");
         std::vector<uint32_t> rank_of(n_acc);
-        ht.accessions.resize(n_acc);
-        for (uint32_t r = 0; r < n_acc; ++r) { rank_of[order[r]] = r; ht.accessions[r].assign(view(order[r])); }
-        lap("  acc: strings");
+        for (uint32_t r = 0; r < n_acc; ++r) rank_of[order[r]] = r;
         HIPCHK(mem.alloc((void**)&d_ranks, (size_t)n_acc * 4));
         HIPCHK(hipMemcpy(d_ranks, rank_of.data(), (size_t)n_acc * 4, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(dict_assign_ids, grid(n_acc), dim3(256), 0, 0, d_atab, d_list_slot, (const uint32_t*)d_ranks, n_acc);
@@ -610,6 +706,7 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         hipLaunchKernelGGL(dict_lookup, grid(n_rows), dim3(256), 0, 0, d_ah, d_apos, n_rows, d_atab, cap - 1, d_text, d_apos, d_arank, d_flags);
         HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
         if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
+        lap("  acc: ranks of the rows");
         mem.free(d_atab); d_atab = nullptr;
         mem.free(d_ah); d_ah = nullptr;
         mem.free(d_apos); d_apos = nullptr;
@@ -623,6 +720,7 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         hipLaunchKernelGGL(check_grouped, grid(n_rows), dim3(256), 0, 0, d_qid, n_rows, d_counter);
         uint32_t unsorted = 0;
         HIPCHK(hipMemcpy(&unsorted, d_counter, 4, hipMemcpyDeviceToHost));
+        lap(unsorted ? "  grouping: check (unsorted)" : "  grouping: check (sorted)");
         if (unsorted) {
             HIPCHK(mem.alloc((void**)&d_perm, (size_t)n_rows * 4)); HIPCHK(mem.alloc((void**)&d_perm2, (size_t)n_rows * 4));
             HIPCHK(mem.alloc((void**)&d_qid2, (size_t)n_rows * 4));
@@ -644,75 +742,112 @@ int load_hits_gpu(const char* text, size_t size, const TaxidMap& row_of, int dev
         HIPCHK(mem.alloc((void**)&d_bs2, (size_t)n_rows * 4)); HIPCHK(mem.alloc((void**)&d_aln2, (size_t)n_rows * 4));
         HIPCHK(mem.alloc((void**)&d_tax2, (size_t)n_rows * 4)); HIPCHK(mem.alloc((void**)&d_arank2, (size_t)n_rows * 4));
         HIPCHK(mem.alloc((void**)&d_pid2, (size_t)n_rows * 8));
+        lap("  grouping: offsets + allocations");
         Cols in{d_bs, d_aln, d_tax, d_arank, d_pid};
         ColsOut out{d_bs2, d_aln2, d_tax2, d_arank2, d_pid2};
         hipLaunchKernelGGL(gather_cols, grid(n_rows), dim3(256), 0, 0, in, out, (const uint32_t*)(unsorted ? d_perm2 : nullptr), n_rows);
     }
     lap("grouping");
 
-    // ---- results to the host
+    // ---- the grouped columns stay on the device for the engine; the host copies are made only on request
     {
-        // The columns come back in 64 MiB pieces copied by a pool of host threads: the first touch of the fresh host pages
-        // costs more than the transfer, and it parallelises (the vectors are resized without initialisation).
-        ht.seg_off.resize((size_t)n_queries + 1);
-        ht.bitscore.resize(n_rows); ht.align_len.resize(n_rows); ht.tax_desc_row.resize(n_rows); ht.acc_rank.resize(n_rows); ht.pident.resize(n_rows);
-        struct Piece { char* dst; const char* src; size_t bytes; };
-        std::vector<Piece> pieces;
-        auto add = [&](void* dst, const void* src, size_t bytes) {
-            for (size_t o = 0; o < bytes; o += (64u << 20)) pieces.push_back({(char*)dst + o, (const char*)src + o, std::min<size_t>(64u << 20, bytes - o)});
-        };
-        add(ht.seg_off.data(), d_seg + n_queries + 1, ((size_t)n_queries + 1) * 8);
-        add(ht.bitscore.data(), d_bs2, (size_t)n_rows * 4); add(ht.align_len.data(), d_aln2, (size_t)n_rows * 4);
-        add(ht.tax_desc_row.data(), d_tax2, (size_t)n_rows * 4); add(ht.acc_rank.data(), d_arank2, (size_t)n_rows * 4);
-        add(ht.pident.data(), d_pid2, (size_t)n_rows * 8);
-        unsigned nt = std::thread::hardware_concurrency();
-        if (const char* env = getenv("BLU_INGEST_THREADS")) nt = (unsigned)atoi(env);
-        nt = std::max(1u, std::min<unsigned>(std::min(nt, 16u), (unsigned)pieces.size()));
-        std::vector<hipError_t> errs(nt, hipSuccess);
-        std::atomic<size_t> next{0};
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nt; ++t)
-            pool.emplace_back([&, t]() {
-                (void)hipSetDevice(device);
-                // (pinning the destination pieces first — hipHostRegister — made it slower: 0.33 s instead of 0.21 s for 2 GB)
-                for (size_t k = next.fetch_add(1); k < pieces.size() && errs[t] == hipSuccess; k = next.fetch_add(1))
-                    errs[t] = hipMemcpy(pieces[k].dst, pieces[k].src, pieces[k].bytes, hipMemcpyDeviceToHost);
-            });
-        for (auto& th : pool) th.join();
-        for (hipError_t e : errs) HIPCHK(e);
         unsigned long long unmatched = 0;
         HIPCHK(hipMemcpy(&unmatched, d_big, 8, hipMemcpyDeviceToHost));
         ht.unmatched = unmatched;
-        // the grouped columns stay on the device for the engine
+        ht.n_hits = n_rows;
+        ht.host_columns = false;
         ht.dev.reset(new DeviceHits());
         ht.dev->device = device; ht.dev->n_hits = n_rows; ht.dev->n_queries = n_queries;
         ht.dev->bitscore = d_bs2; ht.dev->align_len = d_aln2; ht.dev->tax_desc_row = d_tax2; ht.dev->acc_rank = d_arank2; ht.dev->pident = d_pid2;
         ht.dev->seg_off = d_seg + n_queries + 1; ht.dev->seg_block = d_seg;
         for (void* q : {(void*)d_bs2, (void*)d_aln2, (void*)d_tax2, (void*)d_arank2, (void*)d_pid2, (void*)d_seg}) mem.release(q);
+        if (host_columns) {
+            rc = download_columns(ht);
+            if (rc != BLU_OK) goto done;
+            lap("download columns");
+        }
+        // the host strings (query names in id order, accessions in byte order) are built from the packed bytes by a
+        // background thread while the caller goes on to the engine: nothing on the device waits for them
+        ht.query_names.resize(n_queries);
+        ht.accessions.resize(n_acc);
+        unsigned nt = std::thread::hardware_concurrency();
+        if (const char* env = getenv("BLU_INGEST_THREADS")) nt = (unsigned)atoi(env);
+        nt = std::max(1u, std::min(nt, 16u));
+        if ((uint64_t)n_queries + n_acc < 65536) nt = 1;
+        HitTable* const hp = &ht;
+        ht.strings_thread = std::thread([hp, nt, q_bytes = std::move(q_bytes), q_off = std::move(q_off), a_bytes = std::move(a_bytes),
+                                         a_off = std::move(a_off), order = std::move(order)]() {
+            auto work = [&](unsigned t) {
+                const size_t nq = q_off.size() - 1, na = a_off.size() - 1;
+                for (size_t q = nq * t / nt; q < nq * (t + 1) / nt; ++q)
+                    hp->query_names[q].assign(q_bytes.data() + q_off[q], (size_t)(q_off[q + 1] - q_off[q]));
+                for (size_t r = na * t / nt; r < na * (t + 1) / nt; ++r) {
+                    const uint32_t k = order[r];
+                    hp->accessions[r].assign(a_bytes.data() + a_off[k], (size_t)(a_off[k + 1] - a_off[k]));
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
+            work(0);
+            for (auto& th : pool) th.join();
+        });
     }
-    lap("download columns");
 
 done:
     if (rc != BLU_OK) {
-        ht = HitTable();
+        ht.clear();
     }
     return rc;
 }
 
 
+// The columns come back in 64 MiB pieces copied by a pool of host threads: the first touch of the fresh host pages
+// costs more than the transfer, and it parallelises (the vectors are resized without initialisation).
+int download_columns(HitTable& ht) {
+    if (ht.host_columns) return BLU_OK;
+    if (!ht.dev) { set_error("download_columns: no device columns"); return BLU_ERR_INVALID_ARG; }
+    const DeviceHits& d = *ht.dev;
+    const size_t n_rows = d.n_hits, n_queries = d.n_queries;
+    ht.seg_off.resize(n_queries + 1);
+    ht.bitscore.resize(n_rows); ht.align_len.resize(n_rows); ht.tax_desc_row.resize(n_rows); ht.acc_rank.resize(n_rows); ht.pident.resize(n_rows);
+    struct Piece { char* dst; const char* src; size_t bytes; };
+    std::vector<Piece> pieces;
+    auto add = [&](void* dst, const void* src, size_t bytes) {
+        for (size_t o = 0; o < bytes; o += (64u << 20)) pieces.push_back({(char*)dst + o, (const char*)src + o, std::min<size_t>(64u << 20, bytes - o)});
+    };
+    add(ht.seg_off.data(), d.seg_off, (n_queries + 1) * 8);
+    add(ht.bitscore.data(), d.bitscore, n_rows * 4); add(ht.align_len.data(), d.align_len, n_rows * 4);
+    add(ht.tax_desc_row.data(), d.tax_desc_row, n_rows * 4); add(ht.acc_rank.data(), d.acc_rank, n_rows * 4);
+    add(ht.pident.data(), d.pident, n_rows * 8);
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char* env = getenv("BLU_INGEST_THREADS")) nt = (unsigned)atoi(env);
+    nt = std::max(1u, std::min<unsigned>(std::min(nt, 16u), (unsigned)pieces.size()));
+    std::vector<hipError_t> errs(nt, hipSuccess);
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    const int device = d.device;
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([&, t]() {
+            (void)hipSetDevice(device);
+            // (pinning the destination pieces first — hipHostRegister — made it slower: 0.33 s instead of 0.21 s for 2 GB)
+            for (size_t k = next.fetch_add(1); k < pieces.size() && errs[t] == hipSuccess; k = next.fetch_add(1))
+                errs[t] = hipMemcpy(pieces[k].dst, pieces[k].src, pieces[k].bytes, hipMemcpyDeviceToHost);
+        });
+    for (auto& th : pool) th.join();
+    for (hipError_t e : errs)
+        if (e != hipSuccess) { set_error("GPU ingest: column download failed: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
+    ht.host_columns = true;
+    return BLU_OK;
+}
+
 // ---- engine on the resident columns ---------------------------------------------------------------------------
 namespace {
-__global__ void to_engine_rows(uint32_t* __restrict__ rows, uint64_t n, const uint32_t* __restrict__ fwd, uint64_t n_tax) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t r = rows[i];
-    rows[i] = (r == BLU_UNMATCHED_TAXID || r >= n_tax) ? BLU_UNMATCHED_TAXID : fwd[r];
+constexpr uint32_t ROW_NO_TAXID = BLU_UNMATCHED_TAXID;
+__device__ __forceinline__ uint32_t engine_row_of(uint32_t r, const uint32_t* __restrict__ fwd, uint64_t n_tax) {
+    return (r == ROW_NO_TAXID || r >= n_tax) ? ROW_NO_TAXID : fwd[r];
 }
 // k = round(p * 1000) is used only if fl(k / 1000.0) == p bit for bit for every row (the 20 B/hit layout is lossless then)
-__global__ void to_milli(const double* __restrict__ pid, uint64_t n, uint32_t* __restrict__ milli, uint32_t* __restrict__ inexact) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double p = pid[i];
+__device__ __forceinline__ bool milli_of(double p, uint32_t* k_out) {
     bool ok = p >= 0.0 && p < 4.0e6;
     uint32_t k = 0;
     if (ok) {
@@ -720,17 +855,68 @@ __global__ void to_milli(const double* __restrict__ pid, uint64_t n, uint32_t* _
         const double back = (double)k / 1000.0;
         ok = __double_as_longlong(back) == __double_as_longlong(p);
     }
-    milli[i] = k;
-    if (!ok) *inexact = 1u;
+    *k_out = k;
+    return ok;
 }
-}  // namespace
-
-namespace {
-// 16-byte side records of the packed layout (include/blu_consensus.h: blu_hits.packed)
-__global__ void pack_side_records(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ milli, const int32_t* __restrict__ aln,
-                                  const uint32_t* __restrict__ acc, uint64_t n, uint4* __restrict__ rec) {
+// 16-byte side records of the packed layout (include/blu_consensus.h: blu_hits.packed) straight from the ingest's columns
+__global__ void pack_side_records(const uint32_t* __restrict__ desc_row, const double* __restrict__ pid, const int32_t* __restrict__ aln,
+                                  const uint32_t* __restrict__ acc, uint64_t n, const uint32_t* __restrict__ fwd, uint64_t n_tax,
+                                  uint4* __restrict__ rec, uint32_t* __restrict__ inexact) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) rec[i] = make_uint4(rows[i], milli[i], (uint32_t)aln[i], acc[i]);
+    if (i >= n) return;
+    uint32_t k;
+    if (!milli_of(pid[i], &k)) *inexact = 1u;
+    rec[i] = make_uint4(engine_row_of(desc_row[i], fwd, n_tax), k, (uint32_t)aln[i], acc[i]);
+}
+__global__ void to_engine_rows(const uint32_t* __restrict__ desc_row, uint64_t n, const uint32_t* __restrict__ fwd, uint64_t n_tax,
+                               uint32_t* __restrict__ rows) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rows[i] = engine_row_of(desc_row[i], fwd, n_tax);
+}
+__global__ void to_milli(const double* __restrict__ pid, uint64_t n, uint32_t* __restrict__ milli, uint32_t* __restrict__ inexact) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k;
+    if (!milli_of(pid[i], &k)) *inexact = 1u;
+    milli[i] = k;
+}
+
+// Top-score rows of the rendered queries (status 0 / 1), one wave per TOP_QPW consecutive queries: the lanes sweep a
+// segment 64 rows at a time.  Pass 1 counts (out_rows == nullptr), pass 2 writes the rows at the scanned offsets.
+constexpr uint32_t TOP_QPW = 8;
+__global__ __launch_bounds__(256) void top_rows_kernel(const blu_result* __restrict__ recs, const unsigned long long* __restrict__ seg_off,
+                                                       const int32_t* __restrict__ bitscore, uint64_t n_queries,
+                                                       unsigned long long* __restrict__ count, const unsigned long long* __restrict__ off,
+                                                       const uint32_t* __restrict__ desc_row, const uint32_t* __restrict__ acc,
+                                                       const int32_t* __restrict__ aln, const double* __restrict__ pid,
+                                                       TopRow* __restrict__ out_rows, int32_t* __restrict__ out_score) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    for (uint32_t k = 0; k < TOP_QPW; ++k) {
+        const uint64_t q = wave * TOP_QPW + k;
+        if (q >= n_queries) return;
+        const blu_result r = recs[q];
+        unsigned long long n_top = 0;
+        if (r.status < 2 && r.ref_row != 0xFFFFFFFFu) {
+            const int32_t top = bitscore[r.ref_row];
+            const unsigned long long b = seg_off[q], e = seg_off[q + 1];
+            const unsigned long long base = out_rows ? off[q] : 0;
+            for (unsigned long long i0 = b; i0 < e; i0 += 64) {
+                const unsigned long long i = i0 + lane;
+                const bool hit = i < e && bitscore[i] == top;
+                const unsigned long long m = __ballot(hit);
+                if (out_rows && hit) {
+                    const unsigned long long at = base + n_top + __popcll(m & ((1ull << lane) - 1));
+                    TopRow t;
+                    t.row = (uint32_t)i; t.desc_row = desc_row[i]; t.acc_rank = acc[i]; t.align_len = aln[i]; t.pident = pid[i];
+                    out_rows[at] = t;
+                }
+                n_top += __popcll(m);
+            }
+            if (out_score && lane == 0) out_score[q] = top;
+        } else if (out_score && lane == 0) out_score[q] = 0;
+        if (!out_rows && lane == 0) count[q] = n_top;
+    }
 }
 }  // namespace
 
@@ -741,47 +927,87 @@ DeviceHits::~DeviceHits() {
         if (p) (void)hipFree(p);
 }
 
-int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_t* fwd, uint64_t n_tax, int strategy, blu_result* out) {
+int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_t* fwd, uint64_t n_tax, int strategy, blu_result* out,
+                         TopTable* top) {
     int rc = BLU_OK;
     const bool oom_fallback = false;
     std::string* const oom_why = nullptr;
-    uint32_t *d_fwd = nullptr, *d_milli = nullptr, *d_flag = nullptr;
+    uint32_t *d_fwd = nullptr, *d_milli = nullptr, *d_rows = nullptr, *d_flag = nullptr;
     uint4* d_rec = nullptr;
     blu_result* d_out = nullptr;
+    unsigned long long* d_cnt = nullptr;   // [2 (Q + 1)]: counts, then their exclusive scan
+    void* d_tmp = nullptr;
+    TopRow* d_top = nullptr;
+    int32_t* d_score = nullptr;
     uint32_t inexact = 0;
-    const uint64_t n = dev.n_hits;
+    const uint64_t n = dev.n_hits, nq = dev.n_queries;
     auto grid = [](uint64_t m) { return dim3((unsigned)((m + 255) / 256)); };
     if (hipSetDevice(dev.device) != hipSuccess) { set_error("hipSetDevice(%d) failed", dev.device); return BLU_ERR_NO_DEVICE; }
     HIPCHK(hipMalloc((void**)&d_fwd, std::max<uint64_t>(n_tax, 1) * 4));
     HIPCHK(hipMemcpy(d_fwd, fwd, n_tax * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&d_milli, std::max<uint64_t>(n, 1) * 4));
     HIPCHK(hipMalloc((void**)&d_flag, 4));
     HIPCHK(hipMemset(d_flag, 0, 4));
-    HIPCHK(hipMalloc((void**)&d_out, std::max<uint64_t>(dev.n_queries, 1) * sizeof(blu_result)));
-    if (n) {
-        hipLaunchKernelGGL(to_engine_rows, grid(n), dim3(256), 0, 0, dev.tax_desc_row, n, d_fwd, n_tax);
-        hipLaunchKernelGGL(to_milli, grid(n), dim3(256), 0, 0, dev.pident, n, d_milli, d_flag);
-    }
-    HIPCHK(hipMemcpy(&inexact, d_flag, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMalloc((void**)&d_out, std::max<uint64_t>(nq, 1) * sizeof(blu_result)));
     {
         blu_hits h{};
-        h.bitscore = dev.bitscore; h.tax_row = dev.tax_desc_row; h.align_len = dev.align_len; h.acc_rank = dev.acc_rank;
+        h.bitscore = dev.bitscore;
         h.seg_off = (const uint64_t*)dev.seg_off;
-        if (inexact) h.pident = dev.pident;
-        else if (n && hipMalloc((void**)&d_rec, n * 16) == hipSuccess) {
-            // packed layout: a top row's four values in one memory line (if the records do not fit, the columns do)
-            hipLaunchKernelGGL(pack_side_records, grid(n), dim3(256), 0, 0, dev.tax_desc_row, d_milli, dev.align_len, dev.acc_rank, n, d_rec);
-            h.packed = (const uint32_t*)d_rec;
-            h.tax_row = nullptr; h.align_len = nullptr; h.acc_rank = nullptr;
-        } else { (void)hipGetLastError(); h.pident_milli = d_milli; }
-        h.n_hits = n; h.n_queries = dev.n_queries; h.on_device = 1;
+        // packed layout: a top row's four values in one memory line (if the records do not fit, or a perc_identity is not
+        // exactly k/1000, the columns go in)
+        bool packed = n && hipMalloc((void**)&d_rec, n * 16) == hipSuccess;
+        if (!packed) (void)hipGetLastError();
+        if (packed) {
+            hipLaunchKernelGGL(pack_side_records, grid(n), dim3(256), 0, 0, dev.tax_desc_row, dev.pident, dev.align_len, dev.acc_rank, n,
+                               d_fwd, n_tax, d_rec, d_flag);
+            HIPCHK(hipMemcpy(&inexact, d_flag, 4, hipMemcpyDeviceToHost));
+            if (inexact) { (void)hipFree(d_rec); d_rec = nullptr; packed = false; }
+        }
+        if (packed) h.packed = (const uint32_t*)d_rec;
+        else {
+            HIPCHK(hipMalloc((void**)&d_rows, std::max<uint64_t>(n, 1) * 4));
+            if (n) hipLaunchKernelGGL(to_engine_rows, grid(n), dim3(256), 0, 0, dev.tax_desc_row, n, d_fwd, n_tax, d_rows);
+            h.tax_row = d_rows; h.align_len = dev.align_len; h.acc_rank = dev.acc_rank;
+            if (!inexact && n) {   // the records did not fit: milli-percent column
+                HIPCHK(hipMalloc((void**)&d_milli, n * 4));
+                hipLaunchKernelGGL(to_milli, grid(n), dim3(256), 0, 0, dev.pident, n, d_milli, d_flag);
+                HIPCHK(hipMemcpy(&inexact, d_flag, 4, hipMemcpyDeviceToHost));
+            }
+            if (inexact || !n) h.pident = dev.pident; else h.pident_milli = d_milli;
+        }
+        h.n_hits = n; h.n_queries = nq; h.on_device = 1;
         blu_run_params rp{strategy, 0, nullptr};
         rc = blu_consensus_run(tax, &h, &rp, d_out);
         if (rc != BLU_OK) goto done;
     }
-    HIPCHK(hipMemcpy(out, d_out, dev.n_queries * sizeof(blu_result), hipMemcpyDeviceToHost));   // waits for the null stream
+    HIPCHK(hipMemcpy(out, d_out, nq * sizeof(blu_result), hipMemcpyDeviceToHost));   // waits for the null stream
+    if (top) {
+        if (d_rec) { (void)hipFree(d_rec); d_rec = nullptr; }
+        const uint64_t waves = (nq + TOP_QPW - 1) / TOP_QPW;
+        const dim3 g((unsigned)((waves * 64 + 255) / 256));
+        HIPCHK(hipMalloc((void**)&d_cnt, (nq + 1) * 8 * 2));
+        HIPCHK(hipMemset(d_cnt, 0, (nq + 1) * 8 * 2));
+        HIPCHK(hipMalloc((void**)&d_score, std::max<uint64_t>(nq, 1) * 4));
+        if (nq) hipLaunchKernelGGL(top_rows_kernel, g, dim3(256), 0, 0, d_out, dev.seg_off, dev.bitscore, nq, d_cnt, nullptr, nullptr, nullptr,
+                                   nullptr, nullptr, nullptr, nullptr);
+        size_t b = 0;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_cnt, d_cnt + nq + 1, (int)(nq + 1)));
+        HIPCHK(hipMalloc(&d_tmp, std::max<size_t>(b, 16)));
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, b, d_cnt, d_cnt + nq + 1, (int)(nq + 1)));
+        top->off.resize(nq + 1);
+        HIPCHK(hipMemcpy(top->off.data(), d_cnt + nq + 1, (nq + 1) * 8, hipMemcpyDeviceToHost));
+        const uint64_t n_top = top->off[nq];
+        HIPCHK(hipMalloc((void**)&d_top, std::max<uint64_t>(n_top, 1) * sizeof(TopRow)));
+        if (nq) hipLaunchKernelGGL(top_rows_kernel, g, dim3(256), 0, 0, d_out, dev.seg_off, dev.bitscore, nq, nullptr, d_cnt + nq + 1,
+                                   dev.tax_desc_row, dev.acc_rank, dev.align_len, dev.pident, d_top, d_score);
+        top->rows.resize(n_top);
+        top->score.resize(nq);
+        HIPCHK(hipMemcpy(top->rows.data(), d_top, n_top * sizeof(TopRow), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(top->score.data(), d_score, nq * 4, hipMemcpyDeviceToHost));
+    }
 done:
-    for (void* p : {(void*)d_fwd, (void*)d_milli, (void*)d_flag, (void*)d_out, (void*)d_rec}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)d_fwd, (void*)d_milli, (void*)d_rows, (void*)d_flag, (void*)d_out, (void*)d_rec, (void*)d_cnt, d_tmp, (void*)d_top,
+                    (void*)d_score})
+        if (p) (void)hipFree(p);
     return rc;
 }
 

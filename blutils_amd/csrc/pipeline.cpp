@@ -16,6 +16,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <cerrno>
 #include <charconv>
 #include <chrono>
 #include <cmath>
@@ -24,6 +28,7 @@
 #include <cstring>
 #include <deque>
 #include <iterator>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -39,6 +44,13 @@ using namespace blu;
 namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// stage trace of the use-case (BLU_INGEST_TRACE=1): one stderr line per lap
+struct Trace {
+    const bool on = getenv("BLU_INGEST_TRACE") != nullptr;
+    double tp = now_s();
+    void lap(const char* what) { if (on) { const double t = now_s(); fprintf(stderr, "[pipeline] %-26s %.3f s\n", what, t - tp); tp = t; } }
+};
 
 struct MappedFile {
     const char* data = nullptr;
@@ -56,10 +68,12 @@ struct MappedFile {
         data = (const char*)p;
         return true;
     }
-    ~MappedFile() {
+    void close() {
         if (data && size) munmap((void*)data, size);
-        if (fd >= 0) close(fd);
+        if (fd >= 0) ::close(fd);
+        data = nullptr; size = 0; fd = -1;
     }
+    ~MappedFile() { close(); }
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -593,23 +607,30 @@ void parallel_for(unsigned n, unsigned nthreads, F&& f) {
 // and the workers scatter their rows into the grouped table.  The result does not depend on the thread count.
 thread_local int g_last_ingest_path = 0;   // 0 = CPU parser, 1 = GPU parser (blu_last_ingest_path)
 
-int load_hits(const char* path, const Db& db, HitTable& ht, int device = -1) {
+int load_hits(const char* path, const Db& db, HitTable& ht, int device = -1, bool host_columns = true) {
     g_last_ingest_path = 0;
-    MappedFile f;
-    if (!f.open(path)) { set_error("Unexpected error occurred on load table: %s", path); return BLU_ERR_IO; }
     // GPU parser first (ingest_gpu.hip) when a device is given: same columns bit for bit; files it does not handle
-    // (quotes, empty lines, unusual numbers), small files and BLU_INGEST=cpu take the CPU path below
+    // (quotes, empty lines, unusual numbers), small files and BLU_INGEST=cpu take the CPU path below.  The GPU path
+    // reads the file through its descriptor and never maps it.
     {
         const char* mode = getenv("BLU_INGEST");
-        const bool want_gpu = device >= 0 && !(mode && strcmp(mode, "cpu") == 0) && (f.size >= (1u << 20) || (mode && strcmp(mode, "gpu") == 0));
+        struct stat sb;
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0 || fstat(fd, &sb) != 0) { if (fd >= 0) ::close(fd); set_error("Unexpected error occurred on load table: %s", path); return BLU_ERR_IO; }
+        const size_t fsize = (size_t)sb.st_size;
+        const bool want_gpu = device >= 0 && !(mode && strcmp(mode, "cpu") == 0) && (fsize >= (1u << 20) || (mode && strcmp(mode, "gpu") == 0));
+        int rc = BLU_INGEST_FALLBACK;
+        std::string why;
+        if (want_gpu) rc = load_hits_gpu(fd, fsize, db.row_of, device, host_columns, ht, &why);
+        ::close(fd);
         if (want_gpu) {
-            std::string why;
-            const int rc = load_hits_gpu(f.data, f.size, db.row_of, device, ht, &why);
             if (rc == BLU_OK) { g_last_ingest_path = 1; return BLU_OK; }
             if (rc != BLU_INGEST_FALLBACK) return rc;
             if (getenv("BLU_INGEST_TRACE")) fprintf(stderr, "[ingest] GPU parser declined (%s): CPU path\n", why.c_str());
         }
     }
+    MappedFile f;
+    if (!f.open(path)) { set_error("Unexpected error occurred on load table: %s", path); return BLU_ERR_IO; }
     unsigned nthreads = std::thread::hardware_concurrency();
     if (const char* env = getenv("BLU_INGEST_THREADS")) nthreads = (unsigned)atoi(env);
     if (nthreads < 1) nthreads = 1;
@@ -711,32 +732,76 @@ int load_hits(const char* path, const Db& db, HitTable& ht, int device = -1) {
         }
     });
     lap("scatter (parallel)");
+    ht.n_hits = nh;
     return BLU_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // rendering
 // ---------------------------------------------------------------------------------------------------------
-void json_str(std::string& o, const std::string& s) {
-    o.push_back('"');
-    for (unsigned char c : s) {
+// Output buffer of the JSON writer: the std::string calls the writers use (append / push_back / +=), inlined — a
+// record is ~70 short appends, and the out-of-line call per append was a third of the rendering time.
+struct Out {
+    char* base = nullptr;
+    size_t len = 0, cap = 0;
+    Out() = default;
+    Out(const Out&) = delete;
+    Out& operator=(const Out&) = delete;
+    Out(Out&& o) noexcept : base(o.base), len(o.len), cap(o.cap) { o.base = nullptr; o.len = o.cap = 0; }
+    Out& operator=(Out&& o) noexcept { if (this != &o) { free(base); base = o.base; len = o.len; cap = o.cap; o.base = nullptr; o.len = o.cap = 0; } return *this; }
+    ~Out() { free(base); }
+    void reserve(size_t n) {
+        if (n <= cap) return;
+        char* nb = (char*)realloc(base, n);
+        if (!nb) throw std::bad_alloc();
+        base = nb; cap = n;
+    }
+    __attribute__((noinline)) void grow(size_t n) { reserve(std::max(cap * 2, len + n + 4096)); }
+    __attribute__((always_inline)) inline void need(size_t n) { if (__builtin_expect(len + n > cap, 0)) grow(n); }
+    __attribute__((always_inline)) inline void append(const char* p, size_t n) { need(n); memcpy(base + len, p, n); len += n; }
+    __attribute__((always_inline)) inline void append(size_t n, char c) { need(n); memset(base + len, c, n); len += n; }
+    __attribute__((always_inline)) inline void push_back(char c) { need(1); base[len++] = c; }
+    __attribute__((always_inline)) inline Out& operator+=(const char* z) { append(z, __builtin_strlen(z)); return *this; }
+    Out& operator+=(const std::string& z) { append(z.data(), z.size()); return *this; }
+    void assign(const std::string& z) { len = 0; append(z.data(), z.size()); }
+    const char* data() const { return base; }
+    size_t size() const { return len; }
+    void clear() { len = 0; }
+};
+
+// body of a JSON string (no quotes): runs of plain bytes are appended whole
+template <class O>
+void json_esc(O& o, const char* p, size_t n) {
+    size_t i0 = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = (unsigned char)p[i];
+        if (c >= 0x20 && c != '"' && c != '\\') continue;
+        o.append(p + i0, i - i0);
+        i0 = i + 1;
         switch (c) {
             case '"': o += "\\\""; break; case '\\': o += "\\\\"; break; case '\n': o += "\\n"; break;
             case '\r': o += "\\r"; break; case '\t': o += "\\t"; break; case '\b': o += "\\b"; break; case '\f': o += "\\f"; break;
-            default:
-                if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
-                else o.push_back((char)c);
+            default: { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
         }
     }
+    o.append(p + i0, n - i0);
+}
+template <class O>
+void json_str(O& o, std::string_view s) {
+    o.push_back('"');
+    json_esc(o, s.data(), s.size());
     o.push_back('"');
 }
-void json_f64(std::string& o, double v) {   // serde_json: shortest digits that round-trip, integral values keep ".0"
+template <class O>
+void json_f64(O& o, double v) {   // serde_json: shortest digits that round-trip, integral values keep ".0"
     if (!std::isfinite(v)) { o += "null"; return; }
     char b[64];
     auto r = std::to_chars(b, b + sizeof b, v);
-    std::string s(b, r.ptr);
-    if (s.find_first_of(".eE") == std::string::npos) s += ".0";
-    o += s;
+    const size_t n = (size_t)(r.ptr - b);
+    o.append(b, n);
+    bool integral = true;
+    for (size_t i = 0; i < n; ++i) if (b[i] == '.' || b[i] == 'e' || b[i] == 'E') { integral = false; break; }
+    if (integral) o += ".0";
 }
 
 // serde_yaml 0.9 scalar style (third-party emitter, approximated): plain when the text cannot be read back as
@@ -774,171 +839,217 @@ void yaml_str(std::string& o, const std::string& s) {
     }
 }
 
+// The writer's view of one query's result: everything the reference's TaxonomyBean carries, as indices into the
+// taxonomy / accession tables (no strings are built until the text is emitted).  The scratch vectors are reused from
+// record to record by the worker that owns them.
 struct Renderer {
     const Db& db;
-    const HitTable& ht;
+    const std::vector<std::string>& accessions;
+    const TopTable& top;
     const blu_taxonomy* tax;
-    struct Bean { std::string rank_serde, identifier, taxonomy; int32_t occurrences = 0; std::vector<std::string> accessions; uint32_t node = 0; };
-    std::string lineage_string(uint32_t desc_row) const {   // taxonomy_beans_to_string (taxonomy_bean.rs:38-45)
-        std::string s;
-        for (uint64_t i = db.lin_off[desc_row]; i < db.lin_off[desc_row + 1]; ++i) {
-            if (i > db.lin_off[desc_row]) s.push_back(';');
-            s += db.rank_display[db.lin_rank[i]]; s += "__"; s += db.node_ident[db.lin_node[i]];
-        }
-        return s;
-    }
-    std::string rank_serde_of(uint32_t desc_row, uint32_t level) const {
+    struct Bean { uint32_t node, desc_row; int32_t occurrences; const char* rank_serde; };
+    struct Scratch {
+        std::vector<uint32_t> S, bean_of, order;   // S: the top rows (indices into top.rows) in the reference's sorted order
+        std::vector<Bean> beans;                   // first-seen order; `order` = the order they are written in
+        std::string tmp;
+    };
+    struct View {
+        const TopRow* ref = nullptr;
+        uint32_t drow = 0;
+        bool single = false, has_mar = false;
+        const char* reached = nullptr;
+        const char* mar = nullptr;
+    };
+    uint32_t len_of(uint32_t d) const { return (uint32_t)(db.lin_off[d + 1] - db.lin_off[d]); }
+    const char* rank_serde_of(uint32_t desc_row, uint32_t level) const {
         uint16_t codes[BLU_MAX_DEPTH];
         blu_taxonomy_row_cutoffs(tax, desc_row, BLU_MAX_DEPTH, nullptr, nullptr, codes);
         return blu_taxonomy_rank_name(tax, codes[level], 1);
     }
-    struct Fields { std::string reached, mar, identifier, taxonomy; bool has_mar = false, mutated = false, single = false; double pid = 0, bs = 0; std::vector<Bean> beans; };
-    void taxon_yaml(std::string& o, uint64_t q, const blu_result& r) const {
-        std::string js;
-        Fields f;
-        fields(q, r, f);
-        auto kv = [&](const char* k) { o += "    "; o += k; o += ": "; };
-        kv("reachedRank"); yaml_str(o, f.reached); o.push_back('\n');
-        kv("maxAllowedRank"); if (f.has_mar) yaml_str(o, f.mar); else o += "null"; o.push_back('\n');
-        kv("identifier"); yaml_str(o, f.identifier); o.push_back('\n');
-        kv("percIdentity"); json_f64(o, f.pid); o.push_back('\n');
-        kv("bitScore"); json_f64(o, f.bs); o.push_back('\n');
-        kv("taxonomy"); yaml_str(o, f.taxonomy); o.push_back('\n');
-        kv("mutated"); o += f.mutated ? "true" : "false"; o.push_back('\n');
-        kv("singleMatch"); o += f.single ? "true" : "false"; o.push_back('\n');
-        if (f.beans.empty()) { kv("consensusBeans"); o += "[]\n"; return; }
-        o += "    consensusBeans:\n";
-        for (const Bean& b : f.beans) {
-            o += "    - rank: "; yaml_str(o, b.rank_serde); o.push_back('\n');
-            o += "      identifier: "; yaml_str(o, b.identifier); o.push_back('\n');
-            o += "      occurrences: " + std::to_string(b.occurrences) + "\n";
-            o += "      taxonomy: "; yaml_str(o, b.taxonomy); o.push_back('\n');
-            if (b.accessions.empty()) { o += "      accessions: []\n"; continue; }
-            o += "      accessions:\n";
-            for (const std::string& a : b.accessions) { o += "      - "; yaml_str(o, a); o.push_back('\n'); }
+    // taxonomy_beans_to_string (taxonomy_bean.rs:38-45) of the levels in `mask`; json: escaped for a JSON string body
+    template <class O>
+    void lineage(O& o, uint32_t desc_row, uint64_t mask, bool json) const {
+        bool first = true;
+        uint32_t jl = 0;
+        for (uint64_t i = db.lin_off[desc_row]; i < db.lin_off[desc_row + 1]; ++i, ++jl) {
+            if (!((mask >> jl) & 1)) continue;
+            if (!first) o.push_back(';');
+            first = false;
+            const std::string& rk = db.rank_display[db.lin_rank[i]];
+            const std::string& id = db.node_ident[db.lin_node[i]];
+            if (json) { json_esc(o, rk.data(), rk.size()); o += "__"; json_esc(o, id.data(), id.size()); }
+            else { o += rk; o += "__"; o += id; }
         }
     }
-    // the reference's TaxonomyBean fields of one record (shared by the JSON and YAML writers)
-    void fields(uint64_t q, const blu_result& r, Fields& f) const {
-        std::string tmp;
-        taxon_impl(tmp, q, r, false, 0, &f);
-    }
-    // pretty = serde_json::to_string_pretty layout (2-space indent); ind = indentation of the object's own line
-    void taxon(std::string& o, uint64_t q, const blu_result& r, bool pretty, int ind) const { taxon_impl(o, q, r, pretty, ind, nullptr); }
-    void taxon_impl(std::string& o, uint64_t q, const blu_result& r, bool pretty, int ind, Fields* out_fields) const {
-        auto nl = [&](int extra) { if (pretty) { o.push_back('\n'); o.append((size_t)(ind + extra) * 2, ' '); } };
-        const char* colon = pretty ? ": " : ":";
-        const uint32_t row = r.ref_row, drow = ht.tax_desc_row[row];
-        const uint64_t lo = db.lin_off[drow];
-        const uint32_t len = (uint32_t)(db.lin_off[drow + 1] - lo);
-        std::string taxonomy;
-        for (uint32_t jl = 0; jl < len; ++jl)
-            if ((r.level_mask >> jl) & 1) {
-                if (!taxonomy.empty()) taxonomy.push_back(';');
-                taxonomy += db.rank_display[db.lin_rank[lo + jl]]; taxonomy += "__"; taxonomy += db.node_ident[db.lin_node[lo + jl]];
-            }
-        // consensus beans
-        std::vector<Bean> beans;
-        const bool single = r.status == BLU_ST_CONSENSUS_SINGLE;
-        if (single) {   // find_single_query_consensus.rs:123-145
-            Bean b;
-            b.rank_serde = blu_taxonomy_rank_name(tax, r.reached_rank, 1);
-            b.identifier = db.node_ident[r.identifier_node];
-            b.occurrences = 1;
-            b.taxonomy = lineage_string(drow);
-            b.accessions.push_back(ht.accessions[ht.acc_rank[row]]);
-            beans.push_back(std::move(b));
-        } else {
-            const int32_t M = ht.bitscore[row];
-            std::vector<uint32_t> S;
-            for (uint64_t i = ht.seg_off[q]; i < ht.seg_off[q + 1]; ++i) if (ht.bitscore[i] == M) S.push_back((uint32_t)i);
-            auto len_of = [&](uint32_t i) { const uint32_t d = ht.tax_desc_row[i]; return (uint32_t)(db.lin_off[d + 1] - db.lin_off[d]); };
-            std::stable_sort(S.begin(), S.end(), [&](uint32_t a, uint32_t b) {   // find_multi_taxa_consensus.rs:39-54
-                const uint32_t la = len_of(a), lb = len_of(b);
-                if (la != lb) return la < lb;
-                if (ht.pident[a] < ht.pident[b]) return true;
-                if (ht.pident[a] > ht.pident[b]) return false;
-                if (ht.align_len[a] != ht.align_len[b]) return ht.align_len[a] < ht.align_len[b];
-                return ht.acc_rank[a] < ht.acc_rank[b];
-            });
-            const uint32_t lvl = (r.flags & BLU_FLAG_AGREE) ? r.bean_index : (uint32_t)r.bean_index + 1;   // level the scan stopped at
-            for (uint32_t i : S) {   // consensus_result.rs:65-88 fold, first-seen order
-                const uint32_t d = ht.tax_desc_row[i];
-                const uint32_t node = db.lin_node[db.lin_off[d] + lvl];
-                Bean* slot = nullptr;
-                for (Bean& b : beans) if (b.node == node) { slot = &b; break; }
-                if (!slot) {
-                    Bean b;
-                    b.node = node;
-                    b.rank_serde = rank_serde_of(d, lvl);
-                    b.identifier = db.node_ident[node];
-                    b.taxonomy = lineage_string(d);
-                    beans.push_back(std::move(b));
-                    slot = &beans.back();
-                }
-                const std::string& acc = ht.accessions[ht.acc_rank[i]];
-                if (slot->accessions.empty() || slot->accessions.back() != acc) slot->accessions.push_back(acc);   // extend + dedup()
-                slot->occurrences += 1;
-            }
-            std::stable_sort(beans.begin(), beans.end(), [](const Bean& a, const Bean& b) {   // build_blast_consensus_identity.rs:49-60
-                if (a.occurrences != b.occurrences) return a.occurrences > b.occurrences;
-                return a.identifier < b.identifier;
-            });
+    void compute(uint64_t q, const blu_result& r, Scratch& sc, View& v) const {
+        const uint64_t b = top.off[q], e = top.off[q + 1];
+        const TopRow* rows = top.rows.data();
+        v.ref = rows + b;
+        for (uint64_t i = b; i < e; ++i) if (rows[i].row == r.ref_row) { v.ref = rows + i; break; }
+        v.drow = v.ref->desc_row;
+        v.single = r.status == BLU_ST_CONSENSUS_SINGLE;
+        v.reached = blu_taxonomy_rank_name(tax, r.reached_rank, 1);
+        v.has_mar = r.max_allowed_level != BLU_NONE_U8;
+        if (v.has_mar) {
+            uint8_t isdef[BLU_MAX_DEPTH]; uint16_t codes[BLU_MAX_DEPTH];
+            blu_taxonomy_row_cutoffs(tax, v.drow, BLU_MAX_DEPTH, nullptr, isdef, codes);
+            // DefaultRank(rank) -> rank (serde name); NonDefaultRank(name) -> Other(name) (build_blast_consensus_identity.rs:22-30)
+            v.mar = blu_taxonomy_rank_name(tax, codes[r.max_allowed_level], isdef[r.max_allowed_level] ? 1 : 0);
         }
-        if (out_fields) {
-            Fields& f = *out_fields;
-            f.reached = blu_taxonomy_rank_name(tax, r.reached_rank, 1);
-            f.has_mar = r.max_allowed_level != BLU_NONE_U8;
-            if (f.has_mar) {
-                uint8_t isdef[BLU_MAX_DEPTH]; uint16_t codes[BLU_MAX_DEPTH];
-                blu_taxonomy_row_cutoffs(tax, drow, BLU_MAX_DEPTH, nullptr, isdef, codes);
-                f.mar = blu_taxonomy_rank_name(tax, codes[r.max_allowed_level], isdef[r.max_allowed_level] ? 1 : 0);
-            }
-            f.identifier = db.node_ident[r.identifier_node];
-            f.taxonomy = taxonomy;
-            f.mutated = (r.flags & BLU_FLAG_MUTATED) != 0;
-            f.single = single;
-            f.pid = ht.pident[row];
-            f.bs = (double)ht.bitscore[row];
-            f.beans = std::move(beans);
+        sc.S.clear(); sc.bean_of.clear(); sc.beans.clear(); sc.order.clear();
+        if (v.single) {   // find_single_query_consensus.rs:123-145
+            sc.S.push_back((uint32_t)(v.ref - rows));
+            sc.bean_of.push_back(0);
+            sc.beans.push_back(Bean{r.identifier_node, v.drow, 1, v.reached});
+            sc.order.push_back(0);
             return;
         }
-        o.push_back('{');
-        nl(1); o += "\"reachedRank\""; o += colon; json_str(o, blu_taxonomy_rank_name(tax, r.reached_rank, 1));
-        o.push_back(','); nl(1); o += "\"maxAllowedRank\""; o += colon;
-        if (r.max_allowed_level == BLU_NONE_U8) o += "null";
-        else {
-            uint8_t isdef[BLU_MAX_DEPTH]; uint16_t codes[BLU_MAX_DEPTH];
-            blu_taxonomy_row_cutoffs(tax, drow, BLU_MAX_DEPTH, nullptr, isdef, codes);
-            // DefaultRank(rank) -> rank (serde name); NonDefaultRank(name) -> Other(name) (build_blast_consensus_identity.rs:22-30)
-            json_str(o, blu_taxonomy_rank_name(tax, codes[r.max_allowed_level], isdef[r.max_allowed_level] ? 1 : 0));
+        for (uint64_t i = b; i < e; ++i) sc.S.push_back((uint32_t)i);
+        std::stable_sort(sc.S.begin(), sc.S.end(), [&](uint32_t x, uint32_t y) {   // find_multi_taxa_consensus.rs:39-54
+            const TopRow &a = rows[x], &c = rows[y];
+            const uint32_t la = len_of(a.desc_row), lc = len_of(c.desc_row);
+            if (la != lc) return la < lc;
+            if (a.pident < c.pident) return true;
+            if (a.pident > c.pident) return false;
+            if (a.align_len != c.align_len) return a.align_len < c.align_len;
+            return a.acc_rank < c.acc_rank;
+        });
+        const uint32_t lvl = (r.flags & BLU_FLAG_AGREE) ? r.bean_index : (uint32_t)r.bean_index + 1;   // level the scan stopped at
+        for (uint32_t i : sc.S) {   // consensus_result.rs:65-88 fold, first-seen order
+            const uint32_t d = rows[i].desc_row;
+            const uint32_t node = db.lin_node[db.lin_off[d] + lvl];
+            uint32_t bi = 0;
+            while (bi < sc.beans.size() && sc.beans[bi].node != node) ++bi;
+            if (bi == sc.beans.size()) sc.beans.push_back(Bean{node, d, 0, rank_serde_of(d, lvl)});
+            sc.bean_of.push_back(bi);
+            sc.beans[bi].occurrences += 1;
         }
-        o.push_back(','); nl(1); o += "\"identifier\""; o += colon; json_str(o, db.node_ident[r.identifier_node]);
-        o.push_back(','); nl(1); o += "\"percIdentity\""; o += colon; json_f64(o, ht.pident[row]);
-        o.push_back(','); nl(1); o += "\"bitScore\""; o += colon; json_f64(o, (double)ht.bitscore[row]);
-        o.push_back(','); nl(1); o += "\"taxonomy\""; o += colon; json_str(o, taxonomy);
-        o.push_back(','); nl(1); o += "\"mutated\""; o += colon; o += (r.flags & BLU_FLAG_MUTATED) ? "true" : "false";
-        o.push_back(','); nl(1); o += "\"singleMatch\""; o += colon; o += single ? "true" : "false";
-        o.push_back(','); nl(1); o += "\"consensusBeans\""; o += colon; o.push_back('[');
-        for (size_t bi = 0; bi < beans.size(); ++bi) {
-            const Bean& b = beans[bi];
-            if (bi) o.push_back(',');
+        for (uint32_t bi = 0; bi < sc.beans.size(); ++bi) sc.order.push_back(bi);
+        std::stable_sort(sc.order.begin(), sc.order.end(), [&](uint32_t x, uint32_t y) {   // build_blast_consensus_identity.rs:49-60
+            const Bean &a = sc.beans[x], &c = sc.beans[y];
+            if (a.occurrences != c.occurrences) return a.occurrences > c.occurrences;
+            return db.node_ident[a.node] < db.node_ident[c.node];
+        });
+    }
+    // the accessions of bean `bi` in the order they were pushed, consecutive repeats dropped (extend + dedup())
+    template <class F>
+    void bean_accessions(const Scratch& sc, uint32_t bi, F&& f) const {
+        uint32_t last = 0;
+        bool any = false;
+        for (size_t k = 0; k < sc.S.size(); ++k) {
+            if (sc.bean_of[k] != bi) continue;
+            const uint32_t a = top.rows[sc.S[k]].acc_rank;
+            if (any && a == last) continue;
+            any = true; last = a;
+            f(accessions[a]);
+        }
+    }
+    void taxon_yaml(std::string& o, uint64_t q, const blu_result& r, Scratch& sc) const {
+        View v;
+        compute(q, r, sc, v);
+        auto kv = [&](const char* k) { o += "    "; o += k; o += ": "; };
+        auto lin = [&](uint32_t d, uint64_t mask) { sc.tmp.clear(); lineage(sc.tmp, d, mask, false); yaml_str(o, sc.tmp); };
+        kv("reachedRank"); yaml_str(o, v.reached); o.push_back('\n');
+        kv("maxAllowedRank"); if (v.has_mar) yaml_str(o, v.mar); else o += "null"; o.push_back('\n');
+        kv("identifier"); yaml_str(o, db.node_ident[r.identifier_node]); o.push_back('\n');
+        kv("percIdentity"); json_f64(o, v.ref->pident); o.push_back('\n');
+        kv("bitScore"); json_f64(o, (double)top.score[q]); o.push_back('\n');
+        kv("taxonomy"); lin(v.drow, r.level_mask); o.push_back('\n');
+        kv("mutated"); o += (r.flags & BLU_FLAG_MUTATED) ? "true" : "false"; o.push_back('\n');
+        kv("singleMatch"); o += v.single ? "true" : "false"; o.push_back('\n');
+        if (sc.beans.empty()) { kv("consensusBeans"); o += "[]\n"; return; }
+        o += "    consensusBeans:\n";
+        for (uint32_t bi : sc.order) {
+            const Bean& b = sc.beans[bi];
+            o += "    - rank: "; yaml_str(o, b.rank_serde); o.push_back('\n');
+            o += "      identifier: "; yaml_str(o, db.node_ident[b.node]); o.push_back('\n');
+            o += "      occurrences: " + std::to_string(b.occurrences) + "\n";
+            o += "      taxonomy: "; lin(b.desc_row, ~0ull); o.push_back('\n');
+            bool any = false;
+            bean_accessions(sc, bi, [&](const std::string& a) {
+                if (!any) o += "      accessions:\n";
+                any = true;
+                o += "      - "; yaml_str(o, a); o.push_back('\n');
+            });
+            if (!any) o += "      accessions: []\n";
+        }
+    }
+    // pretty = serde_json::to_string_pretty layout (2-space indent); ind = indentation of the object's own line
+    template <class O>
+    void taxon(O& o, uint64_t q, const blu_result& r, bool pretty, int ind, Scratch& sc) const {
+        View v;
+        compute(q, r, sc, v);
+        auto nl = [&](int extra) { if (pretty) { o.push_back('\n'); o.append((size_t)(ind + extra) * 2, ' '); } };
+        const char* colon = pretty ? ": " : ":";
+        auto key = [&](int extra, const char* k, bool comma = true) { if (comma) o.push_back(','); nl(extra); o += k; o += colon; };
+        o.push_back('{');
+        key(1, "\"reachedRank\"", false); json_str(o, v.reached);
+        key(1, "\"maxAllowedRank\"");
+        if (v.has_mar) json_str(o, v.mar); else o += "null";
+        key(1, "\"identifier\""); json_str(o, db.node_ident[r.identifier_node]);
+        key(1, "\"percIdentity\""); json_f64(o, v.ref->pident);
+        key(1, "\"bitScore\""); json_f64(o, (double)top.score[q]);
+        key(1, "\"taxonomy\""); o.push_back('"'); lineage(o, v.drow, r.level_mask, true); o.push_back('"');
+        key(1, "\"mutated\""); o += (r.flags & BLU_FLAG_MUTATED) ? "true" : "false";
+        key(1, "\"singleMatch\""); o += v.single ? "true" : "false";
+        key(1, "\"consensusBeans\""); o.push_back('[');
+        bool first_bean = true;
+        for (uint32_t bi : sc.order) {
+            const Bean& b = sc.beans[bi];
+            if (!first_bean) o.push_back(',');
+            first_bean = false;
             nl(2); o.push_back('{');
-            nl(3); o += "\"rank\""; o += colon; json_str(o, b.rank_serde);
-            o.push_back(','); nl(3); o += "\"identifier\""; o += colon; json_str(o, b.identifier);
-            o.push_back(','); nl(3); o += "\"occurrences\""; o += colon; o += std::to_string(b.occurrences);
-            o.push_back(','); nl(3); o += "\"taxonomy\""; o += colon; json_str(o, b.taxonomy);
-            o.push_back(','); nl(3); o += "\"accessions\""; o += colon; o.push_back('[');
-            for (size_t k = 0; k < b.accessions.size(); ++k) { if (k) o.push_back(','); nl(4); json_str(o, b.accessions[k]); }
-            if (!b.accessions.empty()) nl(3);
+            key(3, "\"rank\"", false); json_str(o, b.rank_serde);
+            key(3, "\"identifier\""); json_str(o, db.node_ident[b.node]);
+            key(3, "\"occurrences\""); { char nb[16]; auto rr = std::to_chars(nb, nb + sizeof nb, b.occurrences); o.append(nb, (size_t)(rr.ptr - nb)); }
+            key(3, "\"taxonomy\""); o.push_back('"'); lineage(o, b.desc_row, ~0ull, true); o.push_back('"');
+            key(3, "\"accessions\""); o.push_back('[');
+            bool any = false;
+            bean_accessions(sc, bi, [&](const std::string& a) { if (any) o.push_back(','); any = true; nl(4); json_str(o, a); });
+            if (any) nl(3);
             o.push_back(']');
             nl(2); o.push_back('}');
         }
-        if (!beans.empty()) nl(1);
+        if (!first_bean) nl(1);
         o.push_back(']');
         nl(0); o.push_back('}');
     }
 };
+
+// TopTable from host columns (the CPU ingest, or the staging path of the engine): same content as the device-side
+// compaction in ingest_gpu.hip
+void top_rows_from_columns(const HitTable& ht, const std::vector<blu_result>& recs, unsigned nthreads, TopTable& top) {
+    const size_t nq = recs.size();
+    top.off.resize(nq + 1);
+    top.score.resize(nq);
+    std::vector<uint64_t> cnt(nq, 0);
+    auto slice = [&](unsigned t, unsigned nt, auto&& f) { for (size_t q = nq * t / nt; q < nq * (t + 1) / nt; ++q) f(q); };
+    const unsigned nt = nq < 65536 ? 1 : nthreads;
+    parallel_for(nt, nt, [&](unsigned t) {
+        slice(t, nt, [&](size_t q) {
+            const blu_result& r = recs[q];
+            top.score[q] = 0;
+            if (r.status >= 2 || r.ref_row == 0xFFFFFFFFu) return;
+            const int32_t M = ht.bitscore[r.ref_row];
+            top.score[q] = M;
+            uint64_t c = 0;
+            for (uint64_t i = ht.seg_off[q]; i < ht.seg_off[q + 1]; ++i) c += ht.bitscore[i] == M;
+            cnt[q] = c;
+        });
+    });
+    top.off[0] = 0;
+    for (size_t q = 0; q < nq; ++q) top.off[q + 1] = top.off[q] + cnt[q];
+    top.rows.resize(top.off[nq]);
+    parallel_for(nt, nt, [&](unsigned t) {
+        slice(t, nt, [&](size_t q) {
+            if (!cnt[q]) return;
+            uint64_t at = top.off[q];
+            const int32_t M = top.score[q];
+            for (uint64_t i = ht.seg_off[q]; i < ht.seg_off[q + 1]; ++i)
+                if (ht.bitscore[i] == M) top.rows[at++] = TopRow{(uint32_t)i, ht.tax_desc_row[i], ht.acc_rank[i], ht.align_len[i], ht.pident[i]};
+        });
+    });
+}
 
 std::string uuid_v4() {
     unsigned char b[16];
@@ -964,35 +1075,59 @@ const char* status_site(uint8_t st) {
     }
 }
 
-}  // namespace
+// The serialized document as the pieces the workers rendered, in order: they are copied (or written) in parallel
+// straight from the worker buffers, never concatenated.
+struct Document {
+    std::vector<Out> pieces;
+    bool written = false;      // the pieces went to the output file while they were rendered (and were freed)
+    size_t size() const { size_t n = 0; for (auto& p : pieces) n += p.size(); return n; }
+};
 
-extern "C" {
+bool write_all(int fd, const char* p, size_t left) {
+    while (left) {
+        const ssize_t w = write(fd, p, left);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        p += w; left -= (size_t)w;
+    }
+    return true;
+}
+double thread_cpu_s() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
-int blu_build_consensus_identities(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
-                                   const char* taxonomies_file, const blu_pipeline_params* params, char** out_text,
-                                   size_t* out_len, blu_pipeline_stats* stats) {
-    return blu_build_consensus_identities_cfg(blast_output_file, headers, n_headers, taxonomies_file, params, nullptr, nullptr,
-                                              out_text, out_len, stats);
+unsigned worker_threads() {
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (const char* env = getenv("BLU_INGEST_THREADS")) nthreads = (unsigned)atoi(env);
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 32) nthreads = 32;
+    return nthreads;
 }
 
-static int build_document(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
-                          const char* taxonomies_file, const blu_pipeline_params* params, const char* run_id_text,
-                          const char* config_text, std::string* document, blu_pipeline_stats* stats) {
+// f(k) for k in [0, n), handed out one at a time to `nthreads` workers
+template <class F>
+void parallel_dynamic(size_t n, unsigned nthreads, F&& f) {
+    if (nthreads <= 1 || n <= 1) { for (size_t k = 0; k < n; ++k) f(k); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthreads && t < n; ++t)
+        pool.emplace_back([&]() { for (size_t k = next.fetch_add(1); k < n; k = next.fetch_add(1)) f(k); });
+    for (auto& th : pool) th.join();
+}
+
+// out_path != nullptr: the document is written there (an existing file is replaced, write_blutils_output.rs:57-63) by a
+// writer thread that follows the renderers piece by piece; otherwise the pieces are left in `document`.
+int build_document(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
+                   const char* taxonomies_file, const blu_pipeline_params* params, const char* run_id_text,
+                   const char* config_text, const char* out_path, Document* document, blu_pipeline_stats* stats) {
     if (!blast_output_file || !taxonomies_file || !params || !document) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
     blu_pipeline_stats st{};
+    Trace tr;
+    const unsigned nthreads = worker_threads();
     double t0 = now_s();
     Db db;
     int rc = load_db(taxonomies_file, params->use_taxid != 0, db);     // mod.rs:64
     if (rc != BLU_OK) return rc;
     st.t_load_db_s = now_s() - t0;
-    t0 = now_s();
-    HitTable ht;
-    rc = load_hits(blast_output_file, db, ht, params->device);         // mod.rs:54, 72-82
-    if (rc != BLU_OK) return rc;
-    st.t_load_hits_s = now_s() - t0;
-    st.n_hits = ht.bitscore.size(); st.n_queries = ht.query_names.size(); st.n_taxids = db.taxid.size(); st.n_unmatched_rows = ht.unmatched;
-
-    t0 = now_s();
+    tr.lap("load db");
+    // the taxonomy table (sorted lineages, cutoff tables, upload) is built by a second thread while the hits are ingested
     std::vector<const char*> names;
     for (auto& s : db.rank_raw) names.push_back(s.c_str());
     blu_taxonomy_desc desc{};
@@ -1005,16 +1140,40 @@ static int build_document(const char* blast_output_file, const char* const* head
     desc.rank_names = names.data();
     desc.bad = db.bad.data();
     blu_taxonomy* tax = nullptr;
-    rc = blu_taxonomy_create(&desc, &params->cutoffs, params->device, &tax);
-    if (rc != BLU_OK) return rc;
     std::vector<uint32_t> fwd(std::max<size_t>(db.taxid.size(), 1));
-    blu_taxonomy_row_map(tax, fwd.data(), nullptr);
+    int tax_rc = BLU_OK;
+    std::string tax_err;
+    double t_tax = 0;
+    std::thread tax_thread([&]() {
+        const double ts = now_s();
+        tax_rc = blu_taxonomy_create(&desc, &params->cutoffs, params->device, &tax);
+        if (tax_rc == BLU_OK) blu_taxonomy_row_map(tax, fwd.data(), nullptr);
+        else { char b[1024]; blu_last_error(b, sizeof b); tax_err = b; }
+        t_tax = now_s() - ts;
+    });
+    struct TaxGuard { blu_taxonomy*& t; std::thread& th; ~TaxGuard() { if (th.joinable()) th.join(); if (t) blu_taxonomy_destroy(t); } } tax_guard{tax, tax_thread};
+    t0 = now_s();
+    HitTable ht;
+    rc = load_hits(blast_output_file, db, ht, params->device, /*host_columns=*/false);   // mod.rs:54, 72-82
+    if (rc != BLU_OK) return rc;
+    st.t_load_hits_s = now_s() - t0;
+    tr.lap("load hits");
+    st.n_hits = ht.n_hits; st.n_queries = ht.query_names.size(); st.n_taxids = db.taxid.size(); st.n_unmatched_rows = ht.unmatched;
+
+    t0 = now_s();
+    tax_thread.join();
+    if (tax_rc != BLU_OK) { set_error("%s", tax_err.c_str()); return tax_rc; }
+    if (tr.on) fprintf(stderr, "[pipeline] (taxonomy create, 2nd thread %.3f s)\n", t_tax);
+    tr.lap("wait for the taxonomy");
     std::vector<blu_result> recs(ht.query_names.size());
+    TopTable top;
     bool done_on_device = false;
     if (ht.dev && !recs.empty()) {
-        // the GPU ingest left the grouped columns on the device: the engine reads them in place (if that fails — e.g. no
-        // room for the work buffers — the host copies of the same columns go through the staging path below)
-        done_on_device = device_run_consensus(tax, *ht.dev, fwd.data(), db.taxid.size(), params->strategy, recs.data()) == BLU_OK;   // mod.rs:104-128
+        // the GPU ingest left the grouped columns on the device: the engine reads them in place and only the records and
+        // the top-score rows come back (if that fails — e.g. no room for the work buffers — the columns are downloaded and
+        // go through the staging path below)
+        done_on_device = device_run_consensus(tax, *ht.dev, fwd.data(), db.taxid.size(), params->strategy, recs.data(), &top) == BLU_OK;   // mod.rs:104-128
+        if (!done_on_device) { rc = download_columns(ht); if (rc != BLU_OK) return rc; }
     }
     ht.dev.reset();
     if (!done_on_device) {
@@ -1041,15 +1200,20 @@ static int build_document(const char* blast_output_file, const char* const* head
             h.n_hits = ht.bitscore.size(); h.n_queries = ht.query_names.size(); h.on_device = 0;
             blu_run_params rp{params->strategy, 0, nullptr};
             rc = blu_consensus_run(tax, &h, &rp, recs.data());             // mod.rs:104-128
-            if (rc != BLU_OK) { blu_taxonomy_destroy(tax); return rc; }
+            if (rc != BLU_OK) return rc;
         }
+        top_rows_from_columns(ht, recs, nthreads, top);
     }
     st.t_engine_s = now_s() - t0;
+    tr.lap("engine + top rows");
 
     t0 = now_s();
+    ht.wait_strings();
+    tr.lap("wait for the strings");
     // results + headers without hits (mod.rs:86-102), sorted by query (write_blutils_output.rs:111)
     struct Item { const std::string* name; int64_t q; };
     std::vector<Item> items;
+    items.reserve(ht.query_names.size());
     for (size_t q = 0; q < ht.query_names.size(); ++q) items.push_back({&ht.query_names[q], (int64_t)q});
     std::vector<std::string> extra;
     if (headers) {
@@ -1060,13 +1224,37 @@ static int build_document(const char* blast_output_file, const char* const* head
             if (!have.count(headers[i])) extra.emplace_back(headers[i]);
         for (auto& s : extra) items.push_back({&s, -1});
     }
-    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return *a.name < *b.name; });
+    {
+        // stable sort by name: sorted runs per worker, then a tree of stable merges
+        auto less = [](const Item& a, const Item& b) { return *a.name < *b.name; };
+        const unsigned nt = items.size() < 65536 ? 1 : nthreads;
+        const size_t n = items.size();
+        // BLAST writes its queries in the order of the FASTA file, which is often sorted already: checked first (in slices)
+        std::atomic<bool> sorted{true};
+        parallel_for(nt, nt, [&](unsigned t) {
+            const size_t i0 = n * t / nt, i1 = std::min(n, n * (t + 1) / nt + 1);
+            if (i1 > i0 && !std::is_sorted(items.begin() + i0, items.begin() + i1, less)) sorted = false;
+        });
+        if (sorted) {}
+        else if (nt == 1) std::stable_sort(items.begin(), items.end(), less);
+        else {
+            parallel_for(nt, nt, [&](unsigned t) { std::stable_sort(items.begin() + n * t / nt, items.begin() + n * (t + 1) / nt, less); });
+            for (unsigned w = 1; w < nt; w *= 2) {
+                std::vector<unsigned> heads;
+                for (unsigned t = 0; t + w < nt; t += 2 * w) heads.push_back(t);
+                parallel_for((unsigned)heads.size(), nt, [&](unsigned k) {
+                    const unsigned t = heads[k];
+                    std::inplace_merge(items.begin() + n * t / nt, items.begin() + n * (t + w) / nt, items.begin() + n * std::min(t + 2 * w, nt) / nt, less);
+                });
+            }
+        }
+    }
+    tr.lap("sort by query");
     for (const Item& it : items) {
         if (it.q < 0) continue;
         const uint8_t s = recs[(size_t)it.q].status;
         if (s >= 16 && !params->lenient) {
             set_error("query `%s`: %s", it.name->c_str(), status_site(s));
-            blu_taxonomy_destroy(tax);
             return BLU_ERR_REFERENCE_PANIC;
         }
     }
@@ -1075,70 +1263,132 @@ static int build_document(const char* blast_output_file, const char* const* head
     // write_blutils_output.rs:82-85: the config's run id, or a fresh one
     const std::string run_id = (run_id_text && *run_id_text) ? std::string(run_id_text) : uuid_v4();
     const std::string cfg = (config_text && *config_text) ? std::string(config_text) : std::string();
-    Renderer R{db, ht, tax};
-    std::string o;
-    o.reserve(items.size() * 512);
-    if (pretty) o += "{\n  \"results\": [";
-    else if (doc) o += "{\"results\":[";
-    else { o += cfg.empty() ? "null" : cfg; o.push_back('\n'); }     // JSONL: the config line comes first
+    Renderer R{db, ht.accessions, top, tax};
+    std::vector<Out>& pieces = document->pieces;
+    pieces.clear();
     if (params->out_format == BLU_OUT_YAML) {
-        o.clear();
+        std::string o;
+        Renderer::Scratch sc;
         o += items.empty() ? "results: []\n" : "results:\n";
         for (const Item& it : items) {
             o += "- runId: "; yaml_str(o, run_id); o.push_back('\n');
             o += "  query: "; yaml_str(o, *it.name); o.push_back('\n');
             if (it.q < 0 || recs[(size_t)it.q].status >= 2) { o += "  taxon: null\n"; continue; }
             o += "  taxon:\n";
-            R.taxon_yaml(o, (uint64_t)it.q, recs[(size_t)it.q]);
+            R.taxon_yaml(o, (uint64_t)it.q, recs[(size_t)it.q], sc);
         }
         if (cfg.empty()) o += "config: null\n";
         else { o += "config:\n"; o += cfg; if (o.back() != '\n') o.push_back('\n'); }
-    }
-    if (params->out_format != BLU_OUT_YAML) {
-        // records are independent: slices of the sorted list are rendered by worker threads and concatenated in order
-        unsigned nthreads = std::thread::hardware_concurrency();
-        if (const char* env = getenv("BLU_INGEST_THREADS")) nthreads = (unsigned)atoi(env);
-        if (nthreads < 1) nthreads = 1;
-        if (nthreads > 32) nthreads = 32;
-        if (items.size() < 4096) nthreads = 1;
-        std::vector<std::string> parts(nthreads);
-        auto render_slice = [&](unsigned ti) {
-            std::string& po = parts[ti];
-            const size_t i0 = items.size() * ti / nthreads, i1 = items.size() * (ti + 1) / nthreads;
-            po.reserve((i1 - i0) * 640);
+        pieces.emplace_back();
+        pieces.back().assign(o);
+    } else {
+        // records are independent: blocks of the sorted list are rendered by worker threads, one piece per block; with an
+        // output file a writer thread sends the finished pieces out in order while the later ones are being rendered
+        const size_t block = 4096, n_blocks = (items.size() + block - 1) / block;
+        pieces.resize(n_blocks + 2);
+        Out& head = pieces.front();
+        if (pretty) head += "{\n  \"results\": [";
+        else if (doc) head += "{\"results\":[";
+        else { if (cfg.empty()) head += "null"; else head += cfg; head.push_back('\n'); }     // JSONL: the config line comes first
+        std::string run_id_json;
+        json_str(run_id_json, run_id);
+        const char* const rid = run_id_json.data();
+        const size_t rid_n = run_id_json.size();
+        int fd = -1;
+        std::thread old_file;   // releases the replaced file's pages off the caller's path
+        struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_old{old_file};
+        if (out_path) {
+            // write_blutils_output.rs:58-63: an existing file is removed, then a new one created.  (Truncating it in place
+            // instead makes ext4 allocate and flush the new blocks inside close().)  The old inode is held open across the
+            // unlink, so that dropping its pages happens in close(old) on a thread of its own.
+            const int old = open(out_path, O_RDONLY);
+            if (old >= 0) {
+                if (unlink(out_path) != 0) { close(old); set_error("cannot replace %s", out_path); return BLU_ERR_IO; }
+                old_file = std::thread([old]() { close(old); });
+            }
+            fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (fd < 0) { set_error("cannot write %s", out_path); return BLU_ERR_IO; }
+        }
+        std::vector<uint8_t> ready(pieces.size(), 0);
+        std::vector<Out> pool;      // buffers the writer is done with, taken again by the renderers (guarded by mu)
+        std::mutex mu;
+        std::condition_variable cv;
+        bool write_ok = true;
+        double t_write = 0;
+        auto publish = [&](size_t k) { { std::lock_guard<std::mutex> lk(mu); ready[k] = 1; } cv.notify_all(); };
+        std::thread writer;
+        if (fd >= 0)
+            writer = std::thread([&]() {
+                for (size_t k = 0; k < pieces.size(); ++k) {
+                    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return ready[k] != 0; }); }
+                    const double ts = now_s();
+                    if (write_ok && !write_all(fd, pieces[k].data(), pieces[k].size())) write_ok = false;
+                    t_write += now_s() - ts;
+                    pieces[k].clear();
+                    std::lock_guard<std::mutex> lk(mu);
+                    pool.push_back(std::move(pieces[k]));
+                }
+            });
+        publish(0);
+        std::atomic<uint64_t> cpu_us{0};
+        parallel_dynamic(n_blocks, items.size() < 4096 ? 1 : nthreads, [&](size_t bk) {
+            thread_local Renderer::Scratch sc;
+            const double tc = thread_cpu_s();
+            Out po;
+            if (fd >= 0) { std::lock_guard<std::mutex> lk(mu); if (!pool.empty()) { po = std::move(pool.back()); pool.pop_back(); } }
+            const size_t i0 = bk * block, i1 = std::min(items.size(), i0 + block);
+            po.reserve((i1 - i0) * (pretty ? 1100 : 520));
+            const int ind = pretty ? 2 : 0;
+            auto nl = [&](int extra) { if (pretty) { po.push_back('\n'); po.append((size_t)(ind + extra) * 2, ' '); } };
+            const char* colon = pretty ? ": " : ":";
             for (size_t ii = i0; ii < i1; ++ii) {
                 const Item& it = items[ii];
-                const int ind = pretty ? 2 : 0;
-                auto nl = [&](int extra) { if (pretty) { po.push_back('\n'); po.append((size_t)(ind + extra) * 2, ' '); } };
-                const char* colon = pretty ? ": " : ":";
                 if (pretty) { if (ii) po.push_back(','); nl(0); }
                 else if (doc && ii) po.push_back(',');
                 po.push_back('{');
-                nl(1); po += "\"runId\""; po += colon; json_str(po, run_id);
+                nl(1); po += "\"runId\""; po += colon; po.append(rid, rid_n);
                 po.push_back(','); nl(1); po += "\"query\""; po += colon; json_str(po, *it.name);
                 po.push_back(','); nl(1); po += "\"taxon\""; po += colon;
                 if (it.q < 0 || recs[(size_t)it.q].status >= 2) po += "null";
-                else R.taxon(po, (uint64_t)it.q, recs[(size_t)it.q], pretty, ind + 1);
+                else R.taxon(po, (uint64_t)it.q, recs[(size_t)it.q], pretty, ind + 1, sc);
                 nl(0); po.push_back('}');
                 if (!doc) po.push_back('\n');
             }
-        };
-        if (nthreads == 1) render_slice(0);
-        else {
-            std::vector<std::thread> pool;
-            for (unsigned ti = 0; ti < nthreads; ++ti) pool.emplace_back(render_slice, ti);
-            for (auto& th : pool) th.join();
+            pieces[bk + 1] = std::move(po);
+            cpu_us += (uint64_t)((thread_cpu_s() - tc) * 1e6);
+            publish(bk + 1);
+        });
+        Out& tail = pieces.back();
+        const std::string cfg_or_null = cfg.empty() ? std::string("null") : cfg;
+        if (pretty) { if (!items.empty()) tail += "\n  "; tail += "],\n  \"config\": "; tail += cfg_or_null; tail += "\n}"; }
+        else if (doc) { tail += "],\"config\":"; tail += cfg_or_null; tail.push_back('}'); }
+        publish(pieces.size() - 1);
+        if (tr.on) fprintf(stderr, "[pipeline] (render workers: %.3f s of CPU time in all)\n", (double)cpu_us.load() * 1e-6);
+        tr.lap("render");
+        if (fd >= 0) {
+            writer.join();
+            tr.lap("wait for the writer");
+            const bool closed = close(fd) == 0;
+            if (!closed || !write_ok) { set_error("cannot write %s", out_path); return BLU_ERR_IO; }
+            document->written = true;
+            if (tr.on) fprintf(stderr, "[pipeline] (writer thread: %.3f s inside write())\n", t_write);
+            tr.lap("close file");
         }
-        for (auto& po : parts) o += po;
     }
-    if (params->out_format == BLU_OUT_YAML) {}
-    else if (pretty) { if (!items.empty()) o += "\n  "; o += "],\n  \"config\": "; o += cfg.empty() ? "null" : cfg; o += "\n}"; }
-    else if (doc) { o += "],\"config\":"; o += cfg.empty() ? "null" : cfg; o.push_back('}'); }
     st.t_render_s = now_s() - t0;
-    blu_taxonomy_destroy(tax);
-    document->swap(o);
     if (stats) *stats = st;
     return BLU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int blu_build_consensus_identities(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
+                                   const char* taxonomies_file, const blu_pipeline_params* params, char** out_text,
+                                   size_t* out_len, blu_pipeline_stats* stats) {
+    return blu_build_consensus_identities_cfg(blast_output_file, headers, n_headers, taxonomies_file, params, nullptr, nullptr,
+                                              out_text, out_len, stats);
 }
 
 int blu_build_consensus_identities_cfg(const char* blast_output_file, const char* const* headers, uint64_t n_headers,
@@ -1148,15 +1398,19 @@ int blu_build_consensus_identities_cfg(const char* blast_output_file, const char
     if (!out_text) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
     *out_text = nullptr;
     if (out_len) *out_len = 0;
-    std::string o;
-    const int rc = build_document(blast_output_file, headers, n_headers, taxonomies_file, params, run_id_text, config_text, &o, stats);
+    Document d;
+    const int rc = build_document(blast_output_file, headers, n_headers, taxonomies_file, params, run_id_text, config_text, nullptr, &d, stats);
     if (rc != BLU_OK) return rc;
-    char* buf = (char*)malloc(o.size() + 1);
+    const size_t total = d.size();
+    char* buf = (char*)malloc(total + 1);
     if (!buf) { set_error("out of memory"); return BLU_ERR_ALLOC; }
-    memcpy(buf, o.data(), o.size());
-    buf[o.size()] = 0;
+    std::vector<size_t> at(d.pieces.size() + 1, 0);
+    for (size_t k = 0; k < d.pieces.size(); ++k) at[k + 1] = at[k] + d.pieces[k].size();
+    parallel_dynamic(d.pieces.size(), total < (1u << 24) ? 1 : worker_threads(),
+                     [&](size_t k) { memcpy(buf + at[k], d.pieces[k].data(), d.pieces[k].size()); });
+    buf[total] = 0;
     *out_text = buf;
-    if (out_len) *out_len = o.size();
+    if (out_len) *out_len = total;
     return BLU_OK;
 }
 
@@ -1165,14 +1419,28 @@ int blu_build_consensus_identities_to_file(const char* blast_output_file, const 
                                            const char* run_id_text, const char* config_text, const char* out_path,
                                            blu_pipeline_stats* stats) {
     if (!out_path) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
-    std::string o;
-    const int rc = build_document(blast_output_file, headers, n_headers, taxonomies_file, params, run_id_text, config_text, &o, stats);
+    Document d;
+    const int rc = build_document(blast_output_file, headers, n_headers, taxonomies_file, params, run_id_text, config_text, out_path, &d, stats);
     if (rc != BLU_OK) return rc;
-    // write_blutils_output.rs:57-63: an existing file is replaced
-    FILE* fp = fopen(out_path, "wb");
-    if (!fp) { set_error("cannot write %s", out_path); return BLU_ERR_IO; }
-    const bool ok = (o.empty() || fwrite(o.data(), o.size(), 1, fp) == 1);
-    if (fclose(fp) != 0 || !ok) { set_error("cannot write %s", out_path); return BLU_ERR_IO; }
+    if (d.written) return BLU_OK;
+    // (YAML: one piece, written here) write_blutils_output.rs:57-63: an existing file is replaced
+    Trace tr;
+    const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { set_error("cannot write %s", out_path); return BLU_ERR_IO; }
+    std::vector<size_t> at(d.pieces.size() + 1, 0);
+    for (size_t k = 0; k < d.pieces.size(); ++k) at[k + 1] = at[k] + d.pieces[k].size();
+    std::atomic<bool> ok{true};
+    parallel_dynamic(d.pieces.size(), at.back() < (1u << 24) ? 1 : std::min(worker_threads(), 16u), [&](size_t k) {
+        const char* p = d.pieces[k].data();
+        size_t left = d.pieces[k].size(), off = at[k];
+        while (left && ok.load(std::memory_order_relaxed)) {
+            const ssize_t w = pwrite(fd, p, left, (off_t)off);
+            if (w < 0) { if (errno == EINTR) continue; ok = false; break; }
+            p += w; left -= (size_t)w; off += (size_t)w;
+        }
+    });
+    if (close(fd) != 0 || !ok) { set_error("cannot write %s", out_path); return BLU_ERR_IO; }
+    tr.lap("write file");
     return BLU_OK;
 }
 
@@ -1199,6 +1467,7 @@ int blu_ingest_only_on(const char* blast_output_file, const char* taxonomies_fil
     st.t_load_hits_s = now_s() - t0;
     st.n_hits = ht.bitscore.size(); st.n_queries = ht.query_names.size(); st.n_taxids = db.taxid.size(); st.n_unmatched_rows = ht.unmatched;
     if (stats) *stats = st;
+    ht.wait_strings();
     if (checksum) {
         uint64_t h = 1469598103934665603ull;
         auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };

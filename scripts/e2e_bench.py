@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the use-case (text table + taxonomy cache in, JSONL document out; SURVEY §8 rows f1 + a + f2):
+
+    python scripts/e2e_bench.py [--queries 2000000] [--hits 50] [--taxa 300000] [--reps 2]
+
+Generates the inputs with scripts/tools/gen_blast.c (compiled here with gcc), then runs
+blu_build_consensus_identities_to_file in a FRESH process per repetition, so that HIP start-up is inside the wall
+time, with the stage trace (BLU_INGEST_TRACE) on.  The number quoted in DESIGN.md is queries / wall of the call.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--queries", type=int, default=2000000)
+    ap.add_argument("--hits", type=int, default=50)
+    ap.add_argument("--taxa", type=int, default=300000)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--accessions", default="clustered", choices=["clustered", "uniform"])
+    ap.add_argument("--dir", default="/tmp/blu_e2e")
+    ap.add_argument("--format", default="jsonl")
+    ap.add_argument("--keep-output", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(args.dir, exist_ok=True)
+    gen = os.path.join(args.dir, "gen_blast")
+    subprocess.run(["gcc", "-O2", "-o", gen, os.path.join(ROOT, "scripts", "tools", "gen_blast.c")], check=True)
+    tj, cache = os.path.join(args.dir, "tax.blutils.json"), os.path.join(args.dir, "tax.blucache")
+    bt = os.path.join(args.dir, f"blast.{args.queries}x{args.hits}.{args.accessions}.tsv")
+    t0 = time.time()
+    subprocess.run([gen, "db", tj, str(args.taxa)], check=True)
+    if not os.path.exists(bt):
+        subprocess.run([gen, "table", bt, str(args.queries), str(args.hits), str(args.taxa), "1", args.accessions], check=True)
+    from blutils_amd import pipeline
+    pipeline.build_db_cache(tj, cache, False)
+    size = os.path.getsize(bt)
+    print(f"inputs: {args.queries} queries x {args.hits} hits = {size / 1e9:.2f} GB of text, {args.taxa} taxids; set up in {time.time() - t0:.1f} s",
+          flush=True)
+    outp = os.path.join(args.dir, "consensus." + args.format)
+    code = ("import sys, json, time; sys.path.insert(0, %r); from blutils_amd import pipeline; t0 = time.perf_counter(); "
+            "_, st = pipeline.build_consensus_identities(%r, %r, 'bacteria', 'relaxed', out_format=%r, lenient=True, parse=False, out_path=%r); "
+            "st['wall_s'] = time.perf_counter() - t0; print(json.dumps(st))" % (ROOT, bt, cache, args.format, outp))
+    best = None
+    for rep in range(args.reps):
+        env = dict(os.environ, BLU_INGEST_TRACE="1")
+        t0 = time.perf_counter()
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        proc_s = time.perf_counter() - t0
+        if p.returncode != 0:
+            print(p.stdout[-2000:], p.stderr[-4000:])
+            raise SystemExit(1)
+        st = json.loads(p.stdout.strip().splitlines()[-1])
+        out_mb = os.path.getsize(outp) / 1e6
+        print(f"rep {rep}: call {st['wall_s']:.3f} s = {st['n_queries'] / st['wall_s'] / 1e6:.2f} Mq/s end to end "
+              f"(process {proc_s:.2f} s incl. python + import); db {st['t_load_db_s']:.3f} | ingest {st['t_load_hits_s']:.3f} | "
+              f"engine {st['t_engine_s']:.3f} | render {st['t_render_s']:.3f}; {out_mb:.0f} MB out", flush=True)
+        for l in p.stderr.splitlines():
+            if l.startswith("["):
+                print("    " + l)
+        if best is None or st["wall_s"] < best["wall_s"]:
+            best = st
+    print(json.dumps({"e2e_mqps": best["n_queries"] / best["wall_s"] / 1e6, "wall_s": best["wall_s"], "queries": best["n_queries"],
+                      "rows": best["n_hits"], "text_gb": size / 1e9}))
+    if not args.keep_output and os.path.exists(outp):
+        os.remove(outp)
+
+
+if __name__ == "__main__":
+    main()

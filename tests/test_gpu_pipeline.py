@@ -271,3 +271,37 @@ def test_golden_taxon_objects_leave_the_product_writer_byte_for_byte(tmp_path, g
             same_bytes += 1
     print(f"[golden writer] {same_content} of {len(cases)} objects reproduce in content, {same_bytes} of them byte for byte")
     assert same_bytes == same_content and same_bytes >= 100
+
+
+def test_large_unsorted_table_streams_to_a_file_in_query_order(tmp_path):
+    """70 000 queries whose names are not in file order: the parallel sort-and-merge of the result list, the writer thread
+    that follows the renderers (out_path) and the replacement of an existing output file — the file must hold exactly
+    the text the in-memory call returns, in byte order of the query names (write_blutils_output.rs:58-63, 111)."""
+    import re
+    nq, taxa = 70000, 3000
+    tj = tmp_path / "t.json"
+    tj.write_text(json.dumps({"blutilsVersion": "8.3.1", "sourceDatabase": "synthetic", "taxonomies": [
+        {"taxid": 1000 + t, "rank": "species", "numericLineage": f"d__2;f__{t // 96};g__{t // 12};s__{1000 + t}",
+         "textLineage": f"d__bacteria;f__fam{t // 96};g__gen{t // 12};s__sp{t}", "accessions": []} for t in range(taxa)]}))
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(nq)
+    sub = (np.repeat(rng.integers(0, taxa, nq), 3) + rng.integers(0, 12, 3 * nq)) % taxa
+    pid = rng.integers(80000, 100001, 3 * nq)
+    bs = np.repeat(rng.integers(200, 2000, nq), 3) - rng.integers(0, 2, 3 * nq)   # ties in about half of the top groups
+    bt = tmp_path / "b.tsv"
+    bt.write_text("".join(f"r{perm[i // 3]:07d}\tNR_{sub[i]:06d}.1\t{1000 + sub[i]}\t{pid[i] // 1000}.{pid[i] % 1000:03d}\t400\t3\t1\t1\t400\t5\t404\t1e-120\t{bs[i]}\n"
+                          for i in range(3 * nq)))
+    assert os.path.getsize(bt) > (1 << 20)
+    raw, st = pipeline.build_consensus_identities(str(bt), str(tj), "bacteria", "relaxed", out_format="jsonl", lenient=True, parse=False)
+    assert st["n_queries"] == nq and pipeline.last_ingest_path() == "gpu"
+    lines = raw.splitlines()
+    assert lines[0] == "null" and len(lines) == nq + 1
+    names = [json.loads(l)["query"] for l in lines[1:]]
+    assert names == sorted(f"r{k:07d}" for k in range(nq))
+    strip = lambda s: re.sub(r'"runId":"[0-9a-f-]+"', '"runId":"x"', s)
+    outp = tmp_path / "consensus.jsonl"
+    outp.write_text("an older result\n" * 100000)
+    for _ in range(2):   # the second run replaces the first run's file
+        _, st2 = pipeline.build_consensus_identities(str(bt), str(tj), "bacteria", "relaxed", out_format="jsonl", lenient=True, parse=False,
+                                                     out_path=str(outp))
+        assert strip(outp.read_text()) == strip(raw)
