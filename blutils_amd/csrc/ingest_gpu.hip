@@ -5,7 +5,9 @@
 // taxid), for files in the plain form BLAST writes; any other file (quotes, empty lines, odd numbers) is handed back
 // to the CPU path untouched (BLU_INGEST_FALLBACK).
 //
-// Stages (all on the handle's device, default stream):
+// Stages (all on the handle's device; the kernels on the default stream):
+//   0. upload          pread() into pinned staging slots -> HBM, six reader threads with a stream each; the file is
+//                      never mapped into the process
 //   1. line index      newline count per 4 KiB tile -> exclusive scan -> line starts
 //   2. parse           one thread per line: tab scan over aligned 16-byte loads, decimal fast path for the four numeric
 //                      columns (mantissa <= 15 digits and |exp10| <= 22: one IEEE operation, so the value is strtod's),
@@ -17,6 +19,10 @@
 //   4. ids             queries numbered by first row (radix sort of the distinct entries); accessions ranked in byte
 //                      order on the host (only the distinct strings travel) and the ranks uploaded
 //   5. grouping        stable radix sort by query id unless the file is grouped already; gathers; segment offsets
+//   6. hand-over       the grouped columns stay on the device for the engine (host copies only on request); the distinct
+//                      query / accession strings come back packed and a background thread turns them into the host
+//                      tables; after the engine, top_rows_kernel compacts the top-score rows of the rendered queries —
+//                      all the writer reads of the table
 // Library primitives (hipcub scan / radix sort) are used for the bookkeeping; the parsing and dictionary kernels are
 // written here.  HBM-bound byte work: no MFMA.
 #include <hip/hip_runtime.h>
@@ -375,12 +381,16 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // way the function is left.
 struct DeviceArena {
     std::vector<void*> ptrs;
+    // keep: work buffers that are done with are handed back only when the arena goes (on some boxes an allocation that
+    // follows a hipFree of GBs takes 0.1 - 0.4 s per GB: 0.3 s of a 0.7 s ingest); set when the device has room for it
+    bool keep = false;
     hipError_t alloc(void** p, size_t bytes) {
         const hipError_t e = hipMalloc(p, bytes);
         if (e == hipSuccess) ptrs.push_back(*p);
         return e;
     }
     void free(void* p) {
+        if (keep) return;
         auto it = std::find(ptrs.begin(), ptrs.end(), p);
         if (it == ptrs.end()) return;
         (void)hipFree(p);
@@ -471,6 +481,7 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)size * 2.6 + (1ull << 30) > (double)free_b)
             return fallback("a file too large for this device's free memory");
+        mem.keep = (double)size * 4.0 + (4ull << 30) < (double)free_b;
     }
 
     unsigned char* d_text = nullptr;
