@@ -288,7 +288,9 @@ __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
 #ifndef BLU_LONG_COST
 #define BLU_LONG_COST 96u   // lane-steps one query costs in the long pass (half a 64-lane step, not pipelined; 64 / 96 / 128 / 192 measured)
 #endif
+#ifndef MAX_TASK_SEG
 #define MAX_TASK_SEG 512u        // longest segment the stream kernel takes (64 lanes x 4 rows, twice); longer ones go to the worklist
+#endif
 #ifndef BLOCK_B
 #define BLOCK_B 256
 #endif
@@ -928,96 +930,144 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     // result goes to the query's lane of phase 2 (ds_bpermute).  Same rule as phase 2a: the reference row is
                     // the maximum (Relaxed) / minimum (Cautious) of (length, perc_identity, align_length, accession), full ties
                     // settled by the position in the file (the later / the earlier row).
+                    // running result of a lane: best row (BK, bacc, bpos -> brow), smallest (length, pident) word, largest pident
+                    // (bit 31: a pident that does not fit the key), span [dlo, dhi], first parse error as position << 8 | status.
+                    // kmin == all ones: no record yet.
                     uint64_t BK = 0;
-                    uint32_t bacc = 0, bpos = 0, brow = 0, kmin = 0xFFFFFFFFu, pmax = 0, dlo = 0xFFFFFFFFu, dhi = 0;
-                    uint32_t e_pos = 0xFFFFFFFFu, e_kind = 0, have = 0, ovf = 0;
+                    uint32_t bacc = 0, bpos = 0, brow = 0, kmin = 0xFFFFFFFFu, pmax = 0, dlo = 0xFFFFFFFFu, dhi = 0, err = 0xFFFFFFFFu;
+                    auto reset = [&]() { BK = 0; bacc = 0; bpos = 0; brow = 0; kmin = 0xFFFFFFFFu; pmax = 0; dlo = 0xFFFFFFFFu; dhi = 0; err = 0xFFFFFFFFu; };
                     auto better = [&](const uint64_t K, const uint32_t acc, const uint32_t pos, const uint64_t K2, const uint32_t acc2, const uint32_t pos2) {
                         const bool gt = (K > K2) | ((K == K2) & (acc > acc2)), eq = (K == K2) & (acc == acc2);
                         return STRAT == BLU_RELAXED ? (gt | (eq & (pos > pos2))) : ((!gt & !eq) | (eq & (pos < pos2)));
                     };
-                    uint32_t m = mask;
-                    while (__ballot(m != 0u)) {
-                        u32x4 g[4];
-                        uint32_t gp[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const bool on = m != 0u;
-                            const uint32_t hb = on ? 31u - (uint32_t)__builtin_clz(m) : 0u, i = RPL - 1u - hb;   // (mask bit RPL - 1 - i = row i: file order)
-                            m = on ? (m & ~(1u << hb)) : 0u;
-                            gp[j] = on ? sub + i : 0xFFFFFFFFu;
-                            const uint32_t row = row0 + i;
-                            if (PACKED) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, on ? row * 16u : 0xFFFFFFC0u, 0, GATHER_AUX);
-                            else {
-                                const uint32_t o4 = on ? row * 4u : 0xFFFFFFF0u;
-                                g[j].x = __builtin_amdgcn_raw_buffer_load_b32(rs_tax, o4, 0, GATHER_AUX);
-                                g[j].y = __builtin_amdgcn_raw_buffer_load_b32(rs_pid, o4, 0, GATHER_AUX);
-                                g[j].z = __builtin_amdgcn_raw_buffer_load_b32(rs_aln, o4, 0, GATHER_AUX);
-                                g[j].w = __builtin_amdgcn_raw_buffer_load_b32(rs_acc, o4, 0, GATHER_AUX);
-                            }
+                    // one side record (position gp in its segment; on = the lane has one) into the lane's running result
+                    auto take_record = [&](const u32x4 rec, const uint32_t gp, const bool on) {
+                        const uint32_t len = umin(rec.x >> BLU_ROW_BITS, t.max_depth), pos = rec.x & ROW_MASK;
+                        const bool unmatched = pos >= t.n_tax, bad = !unmatched && (rec.x >> BLU_ROW_BITS) == 0;
+                        const uint32_t e = (gp << 8) | (bad ? (uint32_t)BLU_ST_ERR_BAD_LINEAGE : (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID);
+                        err = (on && (unmatched | bad)) ? umin(err, e) : err;
+                        const uint32_t pm = rec.y & ((1u << KEY_PID_BITS) - 1u);
+                        const uint32_t k1 = (len << KEY_PID_BITS) | pm;
+                        const uint64_t K = ((uint64_t)k1 << 32) | (rec.z ^ 0x80000000u);
+                        const bool take = on & ((kmin == 0xFFFFFFFFu) | better(K, rec.w, gp, BK, bacc, bpos));
+                        BK = take ? K : BK; bacc = take ? rec.w : bacc; bpos = take ? gp : bpos; brow = take ? pos : brow;
+                        kmin = on ? umin(kmin, k1) : kmin;
+                        const uint32_t pmo = pm | (rec.y >= (1u << KEY_PID_BITS) ? 0x80000000u : 0u);
+                        pmax = (on && pmo > pmax) ? pmo : pmax;
+                        dlo = on ? umin(dlo, pos) : dlo;
+                        dhi = (on && pos > dhi) ? pos : dhi;
+                    };
+                    auto load_record = [&](const uint32_t row, const bool on) {
+                        u32x4 r;
+                        if (PACKED) r = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, on ? row * 16u : 0xFFFFFFC0u, 0, GATHER_AUX);
+                        else {
+                            const uint32_t o4 = on ? row * 4u : 0xFFFFFFF0u;
+                            r.x = __builtin_amdgcn_raw_buffer_load_b32(rs_tax, o4, 0, GATHER_AUX);
+                            r.y = __builtin_amdgcn_raw_buffer_load_b32(rs_pid, o4, 0, GATHER_AUX);
+                            r.z = __builtin_amdgcn_raw_buffer_load_b32(rs_aln, o4, 0, GATHER_AUX);
+                            r.w = __builtin_amdgcn_raw_buffer_load_b32(rs_acc, o4, 0, GATHER_AUX);
                         }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const bool on = gp[j] != 0xFFFFFFFFu;
-                            const uint32_t len = umin(g[j].x >> BLU_ROW_BITS, t.max_depth), pos = g[j].x & ROW_MASK;
-                            const bool unmatched = on && pos >= t.n_tax, bad = on && !unmatched && (g[j].x >> BLU_ROW_BITS) == 0;
-                            const bool ferr = (unmatched | bad) && gp[j] < e_pos;
-                            e_kind = ferr ? (bad ? (uint32_t)BLU_ST_ERR_BAD_LINEAGE : (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID) : e_kind;
-                            e_pos = ferr ? gp[j] : e_pos;
-                            ovf |= (on && g[j].y >= (1u << KEY_PID_BITS)) ? 1u : 0u;
-                            const uint32_t k1 = (len << KEY_PID_BITS) | (g[j].y & ((1u << KEY_PID_BITS) - 1u));
-                            const uint64_t K = ((uint64_t)k1 << 32) | (g[j].z ^ 0x80000000u);
-                            const bool take = on & ((have == 0u) | better(K, g[j].w, gp[j], BK, bacc, bpos));
-                            have = on ? 1u : have;
-                            BK = take ? K : BK; bacc = take ? g[j].w : bacc; bpos = take ? gp[j] : bpos; brow = take ? pos : brow;
-                            kmin = on ? umin(kmin, k1) : kmin;
-                            const uint32_t pm = g[j].y & ((1u << KEY_PID_BITS) - 1u);
-                            pmax = (on && pm > pmax) ? pm : pmax;
-                            dlo = on ? umin(dlo, pos) : dlo;
-                            dhi = (on && pos > dhi) ? pos : dhi;
-                        }
-                    }
-                    // merge the lanes of a query (2, 4 or 8 of them: quad_perm swaps, then the half-row mirror)
+                        return r;
+                    };
+                    // merge with the lane the DPP control pairs this one with
                     auto merge = [&](auto ctrl) {
                         constexpr int C = decltype(ctrl)::value;
                         const uint64_t K2 = ((uint64_t)(uint32_t)dpp<C>((int)(uint32_t)(BK >> 32)) << 32) | (uint32_t)dpp<C>((int)(uint32_t)BK);
                         const uint32_t acc2 = (uint32_t)dpp<C>((int)bacc), pos2 = (uint32_t)dpp<C>((int)bpos), row2 = (uint32_t)dpp<C>((int)brow);
-                        const uint32_t have2 = (uint32_t)dpp<C>((int)have);
-                        const bool take = (have2 != 0u) & ((have == 0u) | better(K2, acc2, pos2, BK, bacc, bpos));
+                        const uint32_t kmin2 = (uint32_t)dpp<C>((int)kmin);
+                        const bool take = (kmin2 != 0xFFFFFFFFu) & ((kmin == 0xFFFFFFFFu) | better(K2, acc2, pos2, BK, bacc, bpos));
                         BK = take ? K2 : BK; bacc = take ? acc2 : bacc; bpos = take ? pos2 : bpos; brow = take ? row2 : brow;
-                        have |= have2;
-                        kmin = umin(kmin, (uint32_t)dpp<C>((int)kmin));
+                        kmin = umin(kmin, kmin2);
                         const uint32_t pm2 = (uint32_t)dpp<C>((int)pmax); pmax = pm2 > pmax ? pm2 : pmax;
                         dlo = umin(dlo, (uint32_t)dpp<C>((int)dlo));
                         const uint32_t hi2 = (uint32_t)dpp<C>((int)dhi); dhi = hi2 > dhi ? hi2 : dhi;
-                        const uint32_t ep2 = (uint32_t)dpp<C>((int)e_pos), ek2 = (uint32_t)dpp<C>((int)e_kind);
-                        e_kind = ep2 < e_pos ? ek2 : e_kind; e_pos = umin(e_pos, ep2);
-                        ovf |= (uint32_t)dpp<C>((int)ovf);
+                        err = umin(err, (uint32_t)dpp<C>((int)err));
                     };
-                    if (LPQ >= 2) merge(std::integral_constant<int, 0xB1>());
-                    if (LPQ >= 4) merge(std::integral_constant<int, 0x4E>());
-                    if (LPQ >= 8) merge(std::integral_constant<int, 0x141>());
-                    if (LPQ >= 16) merge(std::integral_constant<int, 0x140>());
-                    // the query's lane of phase 2 (lane = query) fetches the result from the first lane of the query's group
+                    // the query's lane of phase 2 (lane = query) fetches the merged result from lane src / 4 (ds_bpermute)
+                    auto deliver = [&](const int src, const bool mine) {
+                        const uint32_t f_khi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(BK >> 32));
+                        const uint32_t f_pos = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)bpos), f_row = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)brow);
+                        const uint32_t f_kmin = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)kmin), f_pmax = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pmax);
+                        const uint32_t f_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dlo), f_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dhi);
+                        const uint32_t f_err = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)err);
+                        // (selects, not branches: conditional stores to these by-reference captures end up in scratch memory)
+                        const bool got = mine && f_kmin != 0xFFFFFFFFu;
+                        const bool g_ovf = got && (f_pmax & 0x80000000u) != 0u, g_err = got && !g_ovf && f_err != 0xFFFFFFFFu, g_ok = got && !g_ovf && !g_err;
+                        dn_flag = g_ovf ? 3u : (g_err ? 2u : (g_ok ? 1u : dn_flag));
+                        dn_err = g_err ? (f_err & 0xFFu) : dn_err;
+                        dn_pos = g_err ? (f_err >> 8) : dn_pos;
+                        if constexpr (PID32) { r_pid = g_ok ? (f_khi & ((1u << KEY_PID_BITS) - 1u)) : r_pid; max_pid = g_ok ? f_pmax : max_pid; }
+                        r_len = g_ok ? (f_khi >> KEY_PID_BITS) : r_len; r_row = g_ok ? f_row : r_row; r_pos = g_ok ? f_pos : r_pos;
+                        minlen = g_ok ? (f_kmin >> KEY_PID_BITS) : minlen; g_lo = g_ok ? f_lo : g_lo; g_hi = g_ok ? f_hi : g_hi;
+                    };
                     const uint32_t tq = (uint32_t)lane;                               // this lane as a query of the task
                     const bool mine = tq >= qb && tq < qn && tq < nq;
-                    const int src = (int)(((mine ? tq - qb : 0u) * LPQ) * 4u);          // byte address of the source lane
-                    const uint32_t f_klo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)BK);
-                    const uint32_t f_khi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(BK >> 32));
-                    const uint32_t f_pos = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)bpos), f_row = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)brow);
-                    const uint32_t f_kmin = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)kmin), f_pmax = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pmax);
-                    const uint32_t f_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dlo), f_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dhi);
-                    const uint32_t f_epos = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)e_pos), f_ekind = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)e_kind);
-                    const uint32_t f_have = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)have), f_ovf = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ovf);
-                    const uint32_t f_gk = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)gk);
-                    (void)f_klo;
-                    if (mine && f_have) {
-                        if (f_ovf) dn_flag = 3;
-                        else if (f_epos != 0xFFFFFFFFu) { dn_flag = 2; dn_err = f_ekind; dn_pos = f_epos; }
-                        else {
-                            dn_flag = 1; dn_k = f_gk;
-                            if constexpr (PID32) { r_pid = f_khi & ((1u << KEY_PID_BITS) - 1u); max_pid = f_pmax; }
-                            r_len = f_khi >> KEY_PID_BITS; r_row = f_row; r_pos = f_pos; minlen = f_kmin >> KEY_PID_BITS; g_lo = f_lo; g_hi = f_hi;
+                    const uint32_t own0 = (mine ? tq - qb : 0u) * LPQ;                 // first scanning lane of this lane's query
+                    if (LPQ <= 4u && 2u * (k0 + k1 + k2 + k3) >= r_hi - r_lo) {
+                        // At least half of the step's rows are top rows (whole groups tied): every row's record is wanted.
+                        // The scanning lanes ("owners": RPL consecutive rows each) are served 16 at a time, FOUR LANES PER OWNER:
+                        // lane 4 a + c takes rows c, 4 + c, 8 + c .. of owner 16 g + a, so a request of the wave is 16 runs of 64
+                        // contiguous bytes instead of 64 scattered 16-byte pieces (all-tied 50-hit table: 1.44 -> 0.63 ms — the
+                        // step was bound by the number of requests, not by their bytes).  The quad merges into the owner's
+                        // result, 4 LPQ lanes into the query's.
+                        const uint32_t c4 = (uint32_t)lane & 3u;
+#pragma nounroll
+                        for (uint32_t g = 0; g < 4u; ++g) {
+                            const int own = (int)((16u * g + ((uint32_t)lane >> 2)) * 4u);
+                            const uint32_t o_row0 = (uint32_t)__builtin_amdgcn_ds_bpermute(own, (int)row0);
+                            const uint32_t o_mask = (uint32_t)__builtin_amdgcn_ds_bpermute(own, (int)mask);
+                            const uint32_t o_sub = (uint32_t)__builtin_amdgcn_ds_bpermute(own, (int)sub);
+                            if (__ballot(o_mask != 0u) == 0ull) continue;
+                            reset();
+                            constexpr uint32_t NF = PACKED ? 4u : 2u;   // requests per lane in flight (a record of the column layout is four loads)
+#pragma unroll
+                            for (uint32_t b0 = 0; b0 < RPL; b0 += 4u * NF) {
+                                if (__ballot(((o_mask >> (RPL - 4u * NF - b0)) & ((1u << (4u * NF)) - 1u)) != 0u) == 0ull) continue;
+                                u32x4 rq[NF];
+#pragma unroll
+                                for (uint32_t j = 0; j < NF; ++j) {
+                                    const uint32_t i = b0 + 4u * j + c4;
+                                    rq[j] = load_record(o_row0 + i, ((o_mask >> (RPL - 1u - i)) & 1u) != 0u);   // (mask bit RPL - 1 - i = row i: file order)
+                                }
+#pragma unroll
+                                for (uint32_t j = 0; j < NF; ++j) {
+                                    const uint32_t i = b0 + 4u * j + c4;
+                                    take_record(rq[j], o_sub + i, ((o_mask >> (RPL - 1u - i)) & 1u) != 0u);
+                                }
+                            }
+                            merge(std::integral_constant<int, 0xB1>());
+                            merge(std::integral_constant<int, 0x4E>());
+                            if (LPQ >= 2) merge(std::integral_constant<int, 0x141>());
+                            if (LPQ >= 4) merge(std::integral_constant<int, 0x140>());
+                            deliver((int)(((own0 & 15u) * 4u) * 4u), mine && (own0 >> 4) == g);
                         }
+                    } else {
+                        // fewer top rows than that (or queries of 8 / 16 scanning lanes): every lane fetches the side records of
+                        // ITS OWN top rows only, four requests in flight, and reduces them as they come; the lanes of a query then merge
+                        uint32_t m = mask;
+                        while (__ballot(m != 0u)) {
+                            u32x4 rq[4];
+                            uint32_t gp[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const bool on = m != 0u;
+                                const uint32_t hb = on ? 31u - (uint32_t)__builtin_clz(m) : 0u, i = RPL - 1u - hb;   // (mask bit RPL - 1 - i = row i: file order)
+                                m = on ? (m & ~(1u << hb)) : 0u;
+                                gp[j] = on ? sub + i : 0xFFFFFFFFu;
+                                rq[j] = load_record(row0 + i, on);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) take_record(rq[j], gp[j], gp[j] != 0xFFFFFFFFu);
+                        }
+                        if (LPQ >= 2) merge(std::integral_constant<int, 0xB1>());
+                        if (LPQ >= 4) merge(std::integral_constant<int, 0x4E>());
+                        if (LPQ >= 8) merge(std::integral_constant<int, 0x141>());
+                        if (LPQ >= 16) merge(std::integral_constant<int, 0x140>());
+                        deliver((int)(own0 * 4u), mine);
+                    }
+                    {
+                        const uint32_t f_gk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(own0 * 4u), (int)gk);
+                        dn_k = (mine && dn_flag == 1u) ? f_gk : dn_k;   // (a query is reduced in one step only: dn_flag is this step's)
                     }
                     if (sub == 0 && gk != 0u) L.meta[qi] = META_DENSE;
                     continue;
