@@ -288,6 +288,9 @@ __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
 #ifndef BLU_LONG_COST
 #define BLU_LONG_COST 96u   // lane-steps one query costs in the long pass (half a 64-lane step, not pipelined; 64 / 96 / 128 / 192 measured)
 #endif
+#ifndef BLU_DENSE_Q
+#define BLU_DENSE_Q 3u      // a dense step reads every record of its rows (four lanes per scanning lane) when at least 1 / BLU_DENSE_Q of them are top rows
+#endif
 #ifndef MAX_TASK_SEG
 #define MAX_TASK_SEG 512u        // longest segment the stream kernel takes (64 lanes x 4 rows, twice); longer ones go to the worklist
 #endif
@@ -1003,8 +1006,10 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
                     const uint32_t tq = (uint32_t)lane;                               // this lane as a query of the task
                     const bool mine = tq >= qb && tq < qn && tq < nq;
                     const uint32_t own0 = (mine ? tq - qb : 0u) * LPQ;                 // first scanning lane of this lane's query
-                    if (LPQ <= 4u && 2u * (k0 + k1 + k2 + k3) >= r_hi - r_lo) {
-                        // At least half of the step's rows are top rows (whole groups tied): every row's record is wanted.
+                    if (LPQ <= 4u && BLU_DENSE_Q * (k0 + k1 + k2 + k3) >= r_hi - r_lo) {
+                        // At least a third of the step's rows are top rows (whole groups tied): reading every record of the step is
+                        // cheaper than picking them out (2 M x 50 hits, first g rows tied: g = 15 / 20 at 4.25 / 4.16 Gq/s, 3.59 / 3.09
+                        // with one half as the bar; g = 50 at 3.4).
                         // The scanning lanes ("owners": RPL consecutive rows each) are served 16 at a time, FOUR LANES PER OWNER:
                         // lane 4 a + c takes rows c, 4 + c, 8 + c .. of owner 16 g + a, so a request of the wave is 16 runs of 64
                         // contiguous bytes instead of 64 scattered 16-byte pieces (all-tied 50-hit table: 1.44 -> 0.63 ms — the

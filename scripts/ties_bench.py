@@ -19,7 +19,7 @@ def timeit(d):
 print("geometric(0.35) top groups: %.3f ms" % timeit(hits.as_dict("packed")))
 # make the top group larger: the top `g` rows of every query share the top score
 bs = hits.bitscore.clone().view(-1, 50)
-for g in (5, 10, 20, 50):
+for g in (5, 10, 15, 20, 25, 30, 40, 50):
     b2 = bs.clone()
     top = b2.max(dim=1, keepdim=True).values
     b2[:, :g] = top
