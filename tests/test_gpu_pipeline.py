@@ -299,6 +299,15 @@ def test_large_unsorted_table_streams_to_a_file_in_query_order(tmp_path):
     names = [json.loads(l)["query"] for l in lines[1:]]
     assert names == sorted(f"r{k:07d}" for k in range(nq))
     strip = lambda s: re.sub(r'"runId":"[0-9a-f-]+"', '"runId":"x"', s)
+    # the CPU ingest (host columns, top-score rows picked on the host, strings cut out of the mapped file) must give the
+    # same document as the GPU ingest (columns left on the device, top-score rows compacted there, strings sent back packed)
+    os.environ["BLU_INGEST"] = "cpu"
+    try:
+        raw_cpu, _ = pipeline.build_consensus_identities(str(bt), str(tj), "bacteria", "relaxed", out_format="jsonl", lenient=True, parse=False)
+        assert pipeline.last_ingest_path() == "cpu"
+    finally:
+        os.environ.pop("BLU_INGEST", None)
+    assert strip(raw_cpu) == strip(raw)
     outp = tmp_path / "consensus.jsonl"
     outp.write_text("an older result\n" * 100000)
     for _ in range(2):   # the second run replaces the first run's file
