@@ -28,6 +28,14 @@ using namespace blu;
         }                                                                          \
     } while (0)
 
+// The stream-kernel kind the handle's last table wanted, as far as the device has reported it (pinned word, read without
+// synchronisation); 0 = classify on the device again: the first calls, and every 64th.
+static uint32_t known_kind(const blu_taxonomy* tax) {
+    const uint64_t call = tax->ws_calls++;
+    if (!tax->ws_kind_host || (call & 63u) == 0) return 0u;
+    return __atomic_load_n(tax->ws_kind_host, __ATOMIC_RELAXED);
+}
+
 extern "C" {
 
 int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_run_params* params,
@@ -54,6 +62,11 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         if (!tax->ws_count) {
             if (hipMalloc((void**)&tax->ws_count, 256) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return BLU_ERR_ALLOC; }
             if (hipMemset(tax->ws_count, 0, 256) != hipSuccess) { set_error("hipMemset(workspace) failed"); return BLU_ERR_HIP; }
+            // (without the pinned word every call classifies its table on the device: slower by two kernel boundaries, not wrong)
+            if (hipHostMalloc((void**)&tax->ws_kind_host, 64, hipHostMallocDefault) == hipSuccess) {
+                *tax->ws_kind_host = 0;
+                if (hipHostGetDevicePointer((void**)&tax->ws_kind_dev, tax->ws_kind_host, 0) != hipSuccess) tax->ws_kind_dev = nullptr;
+            } else { (void)hipGetLastError(); tax->ws_kind_host = nullptr; }
         }
         tax->ws_worklist = nullptr;
         tax->ws_capacity = 0;
@@ -63,7 +76,8 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     if (hits->on_device) {
         HitsDev hd{hits->bitscore, hits->tax_row, hits->pident, hits->pident_milli, hits->packed, hits->align_len, hits->acc_rank, hits->seg_off,
                    hits->n_hits, hits->n_queries};
-        return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count);
+        return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count,
+                                tax->ws_kind_dev, known_kind(tax));
     }
 
     // host pointers: stage over PCIe, run, copy the records back (synchronous).  The table goes over in chunks of whole
@@ -164,7 +178,8 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
             HitsDev hd{(const int32_t*)st.bs, (const uint32_t*)st.tax, (milli || packed) ? nullptr : (const double*)st.pid,
                        milli ? (const uint32_t*)st.pid : nullptr, packed ? (const uint32_t*)st.pid : nullptr, (const int32_t*)st.aln,
                        (const uint32_t*)st.acc, (const uint64_t*)st.seg, cr, cq};
-            rc = launch_consensus(td, hd, params->strategy, (blu_result*)st.out, st.s, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count);
+            rc = launch_consensus(td, hd, params->strategy, (blu_result*)st.out, st.s, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count,
+                                  tax->ws_kind_dev, known_kind(tax));
             if (rc != BLU_OK) goto done;
             if (n_chunks > 1) HIP_TRY(hipEventRecord(kernels_done, st.s));
             HIP_TRY(hipMemcpyAsync(out + st.q0, st.out, cq * sizeof(blu_result), hipMemcpyDeviceToHost, st.s));

@@ -85,8 +85,10 @@ struct HitsDev {
 // launch wrapper implemented in consensus_kernel.hip
 // worklist: n_queries uint32 slots; work_count: {queue length, blocks done}, zero between runs (the worklist kernel
 // leaves them so)
+// kind_dev: device address of a pinned host word the run's classification goes to (may be null); known_kind: 1 / 2 = launch
+// the stream kernel with / without the bit-score ring alone, anything else = classify on the device and launch both
 int launch_consensus(const TaxDev& tax, const HitsDev& hits, int strategy, blu_result* out, void* stream,
-                     int device, int num_cus, uint32_t* worklist, uint32_t* work_count);
+                     int device, int num_cus, uint32_t* worklist, uint32_t* work_count, uint32_t* kind_dev, uint32_t known_kind);
 const char* consensus_kernel_name();
 void consensus_last_geometry(uint32_t* grid, uint32_t* block);
 
@@ -129,4 +131,9 @@ struct blu_taxonomy {
     mutable uint32_t* ws_worklist = nullptr;
     mutable uint32_t* ws_count = nullptr;
     mutable uint64_t ws_capacity = 0;
+    // which stream kernel the handle's last table wanted (consensus_kernel.hip: blu_classify_tasks): a pinned host word the
+    // device writes, its device address, and the number of run calls so far
+    mutable uint32_t* ws_kind_host = nullptr;
+    mutable uint32_t* ws_kind_dev = nullptr;
+    mutable uint64_t ws_calls = 0;
 };

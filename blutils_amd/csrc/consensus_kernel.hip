@@ -94,6 +94,10 @@ __device__ uint32_t g_stamps[8192 * 16];   // [wave][16]: cycles per phase, summ
 #define BLOCK_A 768   // 12 waves per CU (three per SIMD): what the per-wave LDS (ring 8 KiB + list) leaves room for
 #endif
 #define WAVES_A (BLOCK_A / WAVE)
+#ifndef BLOCK_N
+#define BLOCK_N 1024  // the kernel without the ring: 16 waves per CU (four per SIMD, 128 VGPRs)
+#endif
+#define BLU_N_WAVES_PER_SIMD 4
 #ifndef LIST_CAP
 #define LIST_CAP 208       // top-group entries per wave task (64 queries; mean ~183, sigma ~18 at geometric(0.35) groups)
 #endif
@@ -349,10 +353,10 @@ static_assert((RING_ROWS & RING_MASK) == 0 && RING_ROWS >= 2048u, "ring size");
 #define DESC_WORD1(RPL, row0, sub) (((row0) << DESC_SUB_BITS) | ((sub) / (RPL)))
 static_assert(LIST_CAP >= 128 && LIST_CAP_F64 >= 128, "the list area also stages the 64 records of a task");
 
-template <bool F64>
+template <bool F64, bool RING>
 struct WaveLds {
     static constexpr uint32_t CAP = F64 ? LIST_CAP_F64 : LIST_CAP;
-    alignas(16) uint32_t ring[RING_ROWS + RING_PAD];   // bit-scores: row v sits at ring[v & RING_MASK]; the pad mirrors ring[0 .. RING_PAD) so that a lane's run of rows never wraps
+    alignas(16) uint32_t ring[RING ? RING_ROWS + RING_PAD : 4u];   // bit-scores: row v sits at ring[v & RING_MASK]; the pad mirrors ring[0 .. RING_PAD) so that a lane's run of rows never wraps
     // top-group rows of the task's queries in file order: {engine row id (sorted position | length << BLU_ROW_BITS),
     // perc_identity (milli-percent, or the low f64 word), align_length, accession rank} — a side record of the packed
     // layout as it is.  Between phase 1 and the gather of a ring task .x holds the row (relative to the task's first row).
@@ -395,27 +399,36 @@ static_assert(RING_CHUNKS <= 16, "wait_vmcnt covers 0..15 younger chunks");
 #endif
 // LAYOUT: 0 = perc_identity f64 column, 1 = milli-percent u32 column, 2 = packed 16-byte side records
 // {tax_row, pident_milli, align_len, acc_rank} next to the bit-score column
-template <int STRAT, int LAYOUT>
-__global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
-                                                                       uint32_t* __restrict__ worklist,
-                                                                       uint32_t* __restrict__ work_count) {
+// RING = false: the same kernel without the bit-score ring — every task takes the direct-load phase 1 — at 128 VGPRs and
+// 16 waves per CU instead of 168 and 12.  A table whose tasks are mostly of mixed segment lengths (none of them could use
+// the ring) runs on that one: its phase 1 is bound by instruction issue, which a fourth wave per SIMD helps and the
+// ring's registers and LDS do not (C5: 0.626 -> 0.573 ms).  blu_classify_tasks decides per run (work_count[9]); the
+// kernel of the other kind returns at once.
+template <int STRAT, int LAYOUT, bool RING>
+__global__ __launch_bounds__((RING || LAYOUT == 0) ? BLOCK_A : BLOCK_N, (RING || LAYOUT == 0) ? BLU_WAVES_PER_SIMD : BLU_N_WAVES_PER_SIMD)
+void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out, uint32_t* __restrict__ worklist, uint32_t* __restrict__ work_count,
+                                 uint32_t forced) {
     constexpr bool PID32 = LAYOUT != 0, PACKED = LAYOUT == 2;
-    constexpr uint32_t CAP = WaveLds<!PID32>::CAP;   // list entries per wave task
+    constexpr uint32_t BLOCK_T = (RING || LAYOUT == 0) ? BLOCK_A : BLOCK_N, WAVES_T = BLOCK_T / WAVE;   // (the f64 layout does not fit 128 VGPRs)
+    constexpr uint32_t CAP = WaveLds<!PID32, RING>::CAP;   // list entries per wave task
+    // forced: the host launched this kind alone (it remembered the kind of the handle's last table); else both kinds are
+    // in the stream and the one blu_classify_tasks did not pick returns
+    if (!forced && __hip_atomic_load(work_count + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (RING ? 1u : 2u)) return;
     // work_count = {queue length, blocks done, published length}: the first two are zero on entry and on exit
-    __shared__ WaveLds<!PID32> s_lds[WAVES_A];
+    __shared__ WaveLds<!PID32, RING> s_lds[WAVES_T];
     // the distinct cutoff values of this (taxonomy, backbone): a few hundred doubles, read per level in phase 2c
     __shared__ double s_cut[CUT_LDS];
     const bool cut_in_lds = t.n_cutvals <= CUT_LDS;
     if (cut_in_lds) {
-        for (uint32_t i = threadIdx.x; i < t.n_cutvals; i += BLOCK_A) s_cut[i] = t.cutvals[i];
+        for (uint32_t i = threadIdx.x; i < t.n_cutvals; i += BLOCK_T) s_cut[i] = t.cutvals[i];
         __syncthreads();
     }
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-    WaveLds<!PID32>& L = s_lds[wib];
+    WaveLds<!PID32, RING>& L = s_lds[wib];
     const uint64_t n_tasks = (h.n_queries + WAVE - 1) / WAVE;
-    const uint64_t wave = (uint64_t)blockIdx.x * WAVES_A + wib;
-    const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_A;
+    const uint64_t wave = (uint64_t)blockIdx.x * WAVES_T + wib;
+    const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_T;
 
     // ---- the bit-score ring of this wave (see WaveLds).  The table's rows are numbered v = row + mis, where mis (0..3)
     // makes v = 0 fall on a 16-byte boundary of the column; chunk c = rows 256 c .. 256 c + 255 lands in ring slot
@@ -1197,7 +1210,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         // database sequences — a task takes a few rounds instead of sending its queries to the worklist kernel.
         bool pend = (uint32_t)lane < nq;
         uint32_t pend_before = WAVE + 1;
-        if (contiguous) {                                            // this task's chunks; what the task before requested ahead stays
+        if (RING && contiguous) {                                    // this task's chunks; what the task before requested ahead stays
             ring_c0 = (uint32_t)(vbase >> 8);
             rs_ring = ring_desc(ring_c0);
             ring_end = task_nrows ? (uint32_t)((vbase + task_nrows - 1u) >> 8) + 1u - sk_total : ring_c0;
@@ -1236,7 +1249,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
             const uint32_t longest = wave_max_u32(rows > short_seg ? 0u : rows);   // longest streamed segment of the task
             // (BLU_MIXED_RING: tasks that also hold longer segments through the ring, their whole chunks left out — correct
             // (full GPU suite green with it) but no gain on C5, whose steps shrink to a few queries each: off)
-            ring_round = contiguous && longest != 0u && (all_short ? __ballot(rows > short_seg) == 0ull : (bool)BLU_MIXED_RING);
+            ring_round = RING && contiguous && longest != 0u && (all_short ? __ballot(rows > short_seg) == 0ull : (bool)BLU_MIXED_RING);
             uint32_t lpq = 1;
             if (ring_round) {
                 scan_rpl = longest > 32u ? 32u : 16u;                     // rows per lane (measured on C3: 32 -3 %; on 10-hit tables: 16 -2.5 %)
@@ -1280,7 +1293,7 @@ __global__ __launch_bounds__(BLOCK_A, BLU_WAVES_PER_SIMD) void blu_consensus_str
         // requested now and travel while this task finishes (its offsets were requested when this task began).
         const bool last_round = __ballot(pend && (my_end - my_off) != 0ull && (my_end - my_off) <= MAX_TASK_SEG && in_span && (L.meta[lane] & META_SLOW)) == 0ull;
         uint32_t nxt_c0 = 0, nxt_lim = 0;
-        if (last_round && next_task < n_tasks) {
+        if (RING && last_round && next_task < n_tasks) {
             // (opaque to the optimizer: otherwise what follows is hoisted out of the rounds loop to right behind the load and
             // the task would start by waiting for the next task's offsets)
             uint32_t o_lo = (uint32_t)nx_off, o_hi = (uint32_t)(nx_off >> 32), e_lo = (uint32_t)nx_end, e_hi = (uint32_t)(nx_end >> 32);
@@ -1953,6 +1966,43 @@ __global__ __launch_bounds__(BLOCK_B, BLU_B_WAVES_PER_SIMD) void blu_consensus_l
 }
 
 // ===============================================================================
+// Which stream kernel runs this table: a sample of its 64-query tasks (at most 16384 of them, evenly spread) is checked
+// for what the ring needs — offsets ascending, no segment over SHORT_SEG rows.  work_count[9] = 1: the kernel with the
+// ring (most sampled tasks can use it), 2: the one without.  work_count[8] / [10] count the votes and are back at zero
+// when the last thread has decided.  The decision also goes to a word of pinned host memory that belongs to the handle:
+// the next calls on the handle read it (no synchronisation: whatever has arrived) and launch that kind alone — a kernel
+// boundary costs ~20 us, 2 % of a C3 run — and every 64th call asks again.  A stale or wrong kind costs time, not
+// correctness: both kinds compute the same records.
+// ===============================================================================
+__global__ __launch_bounds__(256) void blu_classify_tasks(const uint64_t* __restrict__ seg_off, uint64_t n_queries, uint64_t n_hits,
+                                                          uint64_t n_tasks, uint64_t stride, uint32_t n_sampled, uint32_t* __restrict__ work_count,
+                                                          uint32_t* __restrict__ kind_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sampled) return;
+    const uint64_t task = (uint64_t)i * stride;
+    bool ok = task < n_tasks;
+    if (ok) {
+        const uint64_t q0 = task * WAVE, q1 = (q0 + WAVE) < n_queries ? (q0 + WAVE) : n_queries;
+        uint64_t prev = seg_off[q0];
+        for (uint64_t q = q0; q < q1 && ok; ++q) {
+            const uint64_t e = seg_off[q + 1];
+            ok = e >= prev && e - prev <= SHORT_SEG && e <= n_hits;
+            prev = e;
+        }
+    }
+    if (ok) atomicAdd(work_count + 8, 1u);
+    __threadfence();
+    if (atomicAdd(work_count + 10, 1u) == n_sampled - 1u) {
+        const uint32_t capable = __hip_atomic_load(work_count + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t kind = 2u * capable >= n_sampled ? 1u : 2u;
+        __hip_atomic_store(work_count + 9, kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kind_out) __hip_atomic_store(kind_out, kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (pinned host memory: the next call reads it)
+        __hip_atomic_store(work_count + 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(work_count + 10, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ===============================================================================
 // launch
 // ===============================================================================
 static thread_local uint32_t g_grid = 0, g_block = 0;
@@ -1965,18 +2015,32 @@ void consensus_last_geometry(uint32_t* grid, uint32_t* block) {
 
 template <int STRAT, int LAYOUT>
 static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hipStream_t s, int num_cus,
-                    uint32_t* worklist, uint32_t* work_count) {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blu_consensus_stream_kernel<STRAT, LAYOUT>, BLOCK_A, 0) != hipSuccess || per_cu <= 0)
-        per_cu = 2;
+                    uint32_t* worklist, uint32_t* work_count, uint32_t* kind_dev, uint32_t known_kind) {
     const uint64_t n_tasks = (hits.n_queries + WAVE - 1) / WAVE;
-    const uint64_t want = (n_tasks + WAVES_A - 1) / WAVES_A;
-    const uint64_t cap = (uint64_t)(num_cus > 0 ? num_cus : 256) * (uint64_t)per_cu;
-    uint32_t grid = (uint32_t)(want < cap ? want : cap);
-    if (grid == 0) grid = 1;
-    g_grid = grid;
-    g_block = BLOCK_A;
-    hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT>), dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count);
+    const uint32_t cus = (uint32_t)(num_cus > 0 ? num_cus : 256);
+    if (known_kind != 1u && known_kind != 2u) {
+        const uint64_t stride = (n_tasks + 16383) / 16384;
+        const uint32_t n_sampled = (uint32_t)((n_tasks + stride - 1) / stride);
+        hipLaunchKernelGGL(blu_classify_tasks, dim3((n_sampled + 255) / 256), dim3(256), 0, s, hits.seg_off, hits.n_queries, hits.n_hits, n_tasks, stride,
+                           n_sampled, work_count, kind_dev);
+    }
+    // one block per CU of either kind (LDS: 12 waves with the ring, 16 without); with both in the stream, the kind that
+    // was not picked for this table returns at once
+    const uint32_t forced = (known_kind == 1u || known_kind == 2u) ? 1u : 0u;
+    if (known_kind != 2u) {
+        const uint64_t want = (n_tasks + WAVES_A - 1) / WAVES_A;
+        const uint32_t grid = (uint32_t)(want < cus ? (want ? want : 1) : cus);
+        g_grid = grid;
+        g_block = BLOCK_A;
+        hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT, true>), dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count, forced);
+    }
+    if (known_kind != 1u) {
+        constexpr uint32_t block_n = LAYOUT == 0 ? BLOCK_A : BLOCK_N;
+        const uint64_t want = (n_tasks + (block_n / WAVE) - 1) / (block_n / WAVE);
+        const uint32_t grid = (uint32_t)(want < cus ? (want ? want : 1) : cus);
+        if (known_kind == 2u) { g_grid = grid; g_block = block_n; }
+        hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT, false>), dim3(grid), dim3(block_n), 0, s, hits, tax, out, worklist, work_count, forced);
+    }
     // 32 waves per CU: the kernel is latency-bound per query (block size 256 / 512 / 1024: 1.11 / 1.135 / 1.14 ms on C5)
     const uint32_t grid_b = (uint32_t)(num_cus > 0 ? num_cus : 256) * (2048u / BLOCK_B);
     hipLaunchKernelGGL((blu_consensus_long_kernel<STRAT, LAYOUT>), dim3(grid_b), dim3(BLOCK_B), 0, s, hits, tax, out, worklist, work_count);
@@ -1986,19 +2050,19 @@ static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hip
 }
 
 int launch_consensus(const TaxDev& tax, const HitsDev& hits, int strategy, blu_result* out, void* stream, int device,
-                     int num_cus, uint32_t* worklist, uint32_t* work_count) {
+                     int num_cus, uint32_t* worklist, uint32_t* work_count, uint32_t* kind_dev, uint32_t known_kind) {
     (void)device;
     if (hits.n_queries == 0) return BLU_OK;
     const int layout = hits.packed ? 2 : (hits.pident_milli ? 1 : 0);
     hipStream_t s = (hipStream_t)stream;
     if (strategy == BLU_RELAXED) {
-        if (layout == 2) return launch_t<BLU_RELAXED, 2>(tax, hits, out, s, num_cus, worklist, work_count);
-        if (layout == 1) return launch_t<BLU_RELAXED, 1>(tax, hits, out, s, num_cus, worklist, work_count);
-        return launch_t<BLU_RELAXED, 0>(tax, hits, out, s, num_cus, worklist, work_count);
+        if (layout == 2) return launch_t<BLU_RELAXED, 2>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
+        if (layout == 1) return launch_t<BLU_RELAXED, 1>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
+        return launch_t<BLU_RELAXED, 0>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
     }
-    if (layout == 2) return launch_t<BLU_CAUTIOUS, 2>(tax, hits, out, s, num_cus, worklist, work_count);
-    if (layout == 1) return launch_t<BLU_CAUTIOUS, 1>(tax, hits, out, s, num_cus, worklist, work_count);
-    return launch_t<BLU_CAUTIOUS, 0>(tax, hits, out, s, num_cus, worklist, work_count);
+    if (layout == 2) return launch_t<BLU_CAUTIOUS, 2>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
+    if (layout == 1) return launch_t<BLU_CAUTIOUS, 1>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
+    return launch_t<BLU_CAUTIOUS, 0>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
 }
 
 }  // namespace blu

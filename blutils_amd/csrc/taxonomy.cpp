@@ -448,6 +448,7 @@ void blu_taxonomy_destroy(blu_taxonomy* tax) {
         if (tax->d_kthr) (void)hipFree(tax->d_kthr);
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
         if (tax->ws_count) (void)hipFree(tax->ws_count);
+        if (tax->ws_kind_host) (void)hipHostFree(tax->ws_kind_host);
     }
     delete tax;
 }
