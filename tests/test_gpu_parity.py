@@ -699,3 +699,34 @@ def test_dense_top_groups_in_short_segments(hits_per_query):
                                             pident_milli=pm, packed=packed)
             _assert_records_equal(got, exp)
     assert (exp["status"] == 0).sum() > 500
+
+
+@pytest.mark.parametrize("kind", ["ring", "noring"])
+def test_both_builds_of_the_stream_kernel_give_the_same_records(kind, monkeypatch):
+    """The stream kernel exists with the bit-score ring (168 VGPRs, 12 waves per CU) and without it (128 VGPRs, 16 waves);
+    blu_classify_tasks picks one per table.  Whichever runs, the records are the oracle's: each build is forced
+    (BLU_STREAM_KIND) onto a uniform 50-hit table, a tie-heavy one, a ragged one and a Zipf one — i.e. also onto the tables
+    the classification would have given to the other build — in the packed, milli-percent and f64 layouts."""
+    monkeypatch.setenv("BLU_STREAM_KIND", kind)
+    tax = synth.make_taxonomy(5000, 77)
+    t = _engine_tax(tax, "custom", H.CUSTOM_16S)
+    tables = [synth.make_hits(tax, 4000, 78, 50, p_unmatched=0.002).numpy(),
+              synth.make_hits(tax, 3000, 79, 50, top_group="zymo").numpy(),
+              synth.make_hits(tax, 2500, 80, None, zipf=(1.1, 1, 3000)).numpy()]
+    base = synth.make_hits(tax, 64 * 20, 81, 300).numpy()
+    rng = np.random.default_rng(82)
+    lens = np.minimum(rng.integers(1, 301, 64 * 20), np.repeat(rng.choice([16, 32, 64, 128, 256, 300], 20), 64))
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    take = np.concatenate([np.arange(l) + 300 * i for i, l in enumerate(lens)])
+    tables.append({k: (base[k][take] if k != "seg_off" else seg) for k in base})
+    for h in tables:
+        rows = t.engine_rows(h["tax_row"])
+        pm = np.round(h["pident"] * 1000).astype(np.uint32)
+        h = dict(h, pident=pm / 1000.0)
+        for strategy in ("relaxed", "cautious"):
+            exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S, threads=8)
+            _assert_records_equal(engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], strategy=strategy), exp)
+            for packed in (False, True):
+                got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy=strategy,
+                                                pident_milli=pm, packed=packed)
+                _assert_records_equal(got, exp)
