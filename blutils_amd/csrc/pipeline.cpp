@@ -1168,7 +1168,10 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
     std::vector<blu_result> recs(ht.query_names.size());
     TopTable top;
     bool done_on_device = false;
-    if (ht.dev && !recs.empty()) {
+    // (BLU_PIPELINE_HOST_COLUMNS=1, tests: take the fallback below although the device path would work)
+    const bool force_host = getenv("BLU_PIPELINE_HOST_COLUMNS") != nullptr;
+    if (force_host && ht.dev) { rc = download_columns(ht); if (rc != BLU_OK) return rc; }
+    if (ht.dev && !recs.empty() && !force_host) {
         // the GPU ingest left the grouped columns on the device: the engine reads them in place and only the records and
         // the top-score rows come back (if that fails — e.g. no room for the work buffers — the columns are downloaded and
         // go through the staging path below)

@@ -308,6 +308,15 @@ def test_large_unsorted_table_streams_to_a_file_in_query_order(tmp_path):
     finally:
         os.environ.pop("BLU_INGEST", None)
     assert strip(raw_cpu) == strip(raw)
+    # the fallback of the GPU path (the device could not hold the engine's work buffers): columns downloaded after the GPU
+    # ingest, engine through the host-pointer staging path, top-score rows picked on the host
+    os.environ["BLU_PIPELINE_HOST_COLUMNS"] = "1"
+    try:
+        raw_fb, _ = pipeline.build_consensus_identities(str(bt), str(tj), "bacteria", "relaxed", out_format="jsonl", lenient=True, parse=False)
+        assert pipeline.last_ingest_path() == "gpu"
+    finally:
+        os.environ.pop("BLU_PIPELINE_HOST_COLUMNS", None)
+    assert strip(raw_fb) == strip(raw)
     outp = tmp_path / "consensus.jsonl"
     outp.write_text("an older result\n" * 100000)
     for _ in range(2):   # the second run replaces the first run's file
