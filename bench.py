@@ -120,19 +120,30 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     force_dist = os.environ.get("BLU_BENCH_FORCE_DIST") == "1"   # lets a 1-GPU box rehearse the RCCL path and the N > 1 defaults
+    # BLU_BENCH_SHARE_GPU=1: a rehearsal of the N > 1 logic (one table cut over the ranks, max-over-ranks timing) on a box with
+    # ONE GPU — every rank uses cuda:0 and the ranks meet over gloo (RCCL refuses two ranks on one device).  Its `value` is
+    # not a scaling measurement: the ranks share the card.
+    share_gpu = os.environ.get("BLU_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     distributed = world > 1 or force_dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    cdev = "cpu" if share_gpu else dev               # where the few scalars of the collectives live
     backend = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group(backend="nccl", device_id=torch.device(dev))
-        backend = f"{dist.get_backend()} (RCCL), world_size {dist.get_world_size()}"
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+            backend = f"gloo (rehearsal: {dist.get_world_size()} ranks share one GPU), world_size {dist.get_world_size()}"
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+            backend = f"{dist.get_backend()} (RCCL), world_size {dist.get_world_size()}"
     scaling = args.scaling if args.scaling != "auto" else ("strong" if distributed else "weak")
 
     cfg = dict(synth.CONFIGS[args.config])
@@ -266,7 +277,7 @@ def main():
         elapsed = time.perf_counter() - t_start
         kernel_ms = [a.elapsed_time(b) for a, b in ev]
         if distributed:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         return elapsed, kernel_ms
@@ -275,7 +286,7 @@ def main():
     elapsed, kernel_ms = timed(run_step)
     total_q = Q
     if distributed:
-        tq = torch.tensor([Q], dtype=torch.int64, device=dev)
+        tq = torch.tensor([Q], dtype=torch.int64, device=cdev)
         dist.all_reduce(tq)
         total_q = int(tq.item())
     T_top = count_top_rows(hits)
@@ -291,7 +302,7 @@ def main():
         hits2, hd2, _, _, out2, _ = build_table("weak")
         state["hd"], state["out"] = hd2, out2
         e2, _ = timed(step)
-        tq = torch.tensor([hits2.n_queries], dtype=torch.int64, device=dev)
+        tq = torch.tensor([hits2.n_queries], dtype=torch.int64, device=cdev)
         dist.all_reduce(tq)
         secondary = {"scaling": "weak", "value": int(tq.item()) * args.steps / e2 / 1e6, "unit": "Mqueries/s",
                      "ms_per_step": e2 * 1e3 / args.steps, "queries_per_gpu": hits2.n_queries,
