@@ -242,20 +242,45 @@ __global__ void dict_init(Slot* __restrict__ tab, uint64_t n_slots) {
 __global__ void dict_insert(const unsigned long long* __restrict__ h, uint32_t n, Slot* __restrict__ tab, uint64_t mask, bool only_heads,
                             uint32_t* __restrict__ n_keys, uint32_t* __restrict__ flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long key = h[i];
-    if (only_heads && i > 0 && h[i - 1] == key) return;
-    uint64_t s = key & mask;
-    for (uint32_t probes = 0; probes < 8192; ++probes) {
-        unsigned long long cur = __hip_atomic_load(&tab[s].hash, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == 0) {
-            cur = atomicCAS(&tab[s].hash, 0ull, key);
-            if (cur == 0) { atomicAdd(n_keys, 1u); cur = key; }
-        }
-        if (cur == key) { atomicMin(&tab[s].first_row, i); return; }
-        s = (s + 1) & mask;
+    bool active = i < n;
+    unsigned long long key = 0;
+    if (active) {
+        key = h[i];
+        if (only_heads && i > 0 && h[i - 1] == key) active = false;
     }
-    atomicOr(flags, FB_TABLE_FULL);
+    bool claimed = false, full = false;
+    if (active) {
+        uint64_t s = key & mask;
+        full = true;
+        for (uint32_t probes = 0; probes < 8192; ++probes) {
+            unsigned long long cur = __hip_atomic_load(&tab[s].hash, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == 0) {
+                cur = atomicCAS(&tab[s].hash, 0ull, key);
+                if (cur == 0) { claimed = true; cur = key; }
+            }
+            if (cur == key) {
+                // (first_row only ever decreases: a value read here is an upper bound of the current one, so a row that is not
+                // below it has nothing to store — 100 M rows, 300 k accessions: all but a few of the atomics go)
+                if (__hip_atomic_load(&tab[s].first_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(&tab[s].first_row, i);
+                full = false;
+                break;
+            }
+            s = (s + 1) & mask;
+        }
+    }
+    (void)claimed; (void)n_keys;   // (the keys are counted by dict_count afterwards: one atomic per new key on one word — 2 M
+                                   // of them for a query dictionary — took 18 of this kernel's 19.6 ms)
+    if (full) atomicOr(flags, FB_TABLE_FULL);
+}
+
+// number of occupied slots -> *n_keys (zeroed by the caller): a block reduction, one atomic per block
+__global__ __launch_bounds__(1024) void dict_count(const Slot* __restrict__ tab, uint64_t n_slots, uint32_t* __restrict__ n_keys) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t used = s < n_slots && tab[s].hash != 0ull;
+    typedef hipcub::BlockReduce<uint32_t, 1024> BR;
+    __shared__ typename BR::TempStorage tmp;
+    const uint32_t c = BR(tmp).Sum(used);
+    if (threadIdx.x == 0 && c) atomicAdd(n_keys, c);
 }
 
 // occupied slots: key length and first bytes from the text of their first row; list of (first_row, slot)
@@ -347,9 +372,15 @@ __global__ void iota_u32(uint32_t* __restrict__ v, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = i;
 }
-__global__ void histogram_qid(const uint32_t* __restrict__ qid, uint32_t n, unsigned long long* __restrict__ count) {
+// segment offsets from the query ids in grouped (non-decreasing) order: the first row of every id, and the row count
+// behind the last one.  Every id 0 .. n_queries - 1 occurs (ids are handed out to keys that are in the table).  (A
+// histogram with one atomic per row and a scan did the same in 5.7 ms per 100 M rows; this reads the ids once.)
+__global__ void segment_starts(const uint32_t* __restrict__ qid_sorted, uint32_t n, uint32_t n_queries, unsigned long long* __restrict__ seg_off) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&count[qid[i]], 1ull);
+    if (i >= n) return;
+    const uint32_t q = qid_sorted[i];
+    if (i == 0 || qid_sorted[i - 1] != q) seg_off[q] = i;
+    if (i == n - 1) seg_off[n_queries] = n;
 }
 struct Cols { const int32_t* bs; const int32_t* aln; const uint32_t* tax; const uint32_t* arank; const double* pid; };
 struct ColsOut { int32_t* bs; int32_t* aln; uint32_t* tax; uint32_t* arank; double* pid; };
@@ -606,6 +637,7 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
         hipLaunchKernelGGL(dict_init, grid(cap), dim3(256), 0, 0, d_qtab, cap);   // empty slots, first_row = all ones for atomicMin
         HIPCHK(hipMemset(d_counter, 0, 4));
         hipLaunchKernelGGL(dict_insert, grid(n_rows), dim3(256), 0, 0, d_qh, n_rows, d_qtab, cap - 1, true, d_counter, d_flags);
+        hipLaunchKernelGGL(dict_count, grid(cap, 1024), dim3(1024), 0, 0, d_qtab, cap, d_counter);
         HIPCHK(hipMemcpy(&n_queries, d_counter, 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
         if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
@@ -641,7 +673,7 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
 
     // ---- accession dictionary: distinct count unknown; the table grows until the load stays under one half
     {
-        uint64_t cap = pow2_at_least(std::min<uint64_t>((uint64_t)n_rows * 2 + 16, 1ull << 22));
+        uint64_t cap = pow2_at_least(std::min<uint64_t>((uint64_t)n_rows * 2 + 16, 1ull << 20));   // (32 MB: stays in the caches while 100 M rows probe it; x4 when more than half full)
         for (;;) {
             HIPCHK(mem.alloc((void**)&d_atab, cap * sizeof(Slot)));
             lap("  acc: table allocation");
@@ -649,6 +681,7 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
             HIPCHK(hipMemset(d_counter, 0, 4));
             HIPCHK(hipMemset(d_flags, 0, 4));
             hipLaunchKernelGGL(dict_insert, grid(n_rows), dim3(256), 0, 0, d_ah, n_rows, d_atab, cap - 1, false, d_counter, d_flags);
+            hipLaunchKernelGGL(dict_count, grid(cap, 1024), dim3(1024), 0, 0, d_atab, cap, d_counter);
             HIPCHK(hipMemcpy(&n_acc, d_counter, 4, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
             if (!(h_flags & FB_TABLE_FULL) && (uint64_t)n_acc * 2 <= cap) break;
@@ -745,11 +778,8 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
         }
         HIPCHK(mem.alloc((void**)&d_seg, ((size_t)n_queries + 1) * 8 * 2));
         HIPCHK(hipMemset(d_seg, 0, ((size_t)n_queries + 1) * 8 * 2));
-        hipLaunchKernelGGL(histogram_qid, grid(n_rows), dim3(256), 0, 0, d_qid, n_rows, d_seg);
-        size_t b = 0;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_seg, d_seg + n_queries + 1, (int)(n_queries + 1)));
-        HIPCHK(need_tmp(b));
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, b, d_seg, d_seg + n_queries + 1, (int)(n_queries + 1)));
+        hipLaunchKernelGGL(segment_starts, grid(n_rows), dim3(256), 0, 0, (const uint32_t*)(unsorted ? d_qid2 : d_qid), n_rows, n_queries,
+                           d_seg + n_queries + 1);
         HIPCHK(mem.alloc((void**)&d_bs2, (size_t)n_rows * 4)); HIPCHK(mem.alloc((void**)&d_aln2, (size_t)n_rows * 4));
         HIPCHK(mem.alloc((void**)&d_tax2, (size_t)n_rows * 4)); HIPCHK(mem.alloc((void**)&d_arank2, (size_t)n_rows * 4));
         HIPCHK(mem.alloc((void**)&d_pid2, (size_t)n_rows * 8));
