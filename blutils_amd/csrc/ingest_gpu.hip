@@ -445,14 +445,18 @@ static int upload_file(int fd, size_t size, unsigned char* d_text, int device, s
     const size_t piece = 8u << 20, n_pieces = (size + piece - 1) / piece;
     nt = std::max(1u, std::min<unsigned>(nt, (unsigned)std::max<size_t>(n_pieces, 1)));
     std::atomic<size_t> next{0};
-    std::atomic<int> failed{0};
+    std::atomic<int> failed{0};      // 1: the file could not be read; 2: the staging path could not be set up or used (HIP)
     std::vector<std::string> errs(nt);
     auto work = [&](unsigned t) {
         char* slots = nullptr;
         hipStream_t st = nullptr;
         hipEvent_t ev[2] = {nullptr, nullptr};
         bool busy[2] = {false, false};
-        auto fail = [&](const char* what, hipError_t e) { errs[t] = std::string(what) + ": " + (e == hipSuccess ? strerror(errno) : hipGetErrorString(e)); failed = 1; };
+        auto fail = [&](const char* what, hipError_t e) {
+            errs[t] = std::string(what) + ": " + (e == hipSuccess ? strerror(errno) : hipGetErrorString(e));
+            int none = 0;
+            failed.compare_exchange_strong(none, e == hipSuccess ? 1 : 2);
+        };
         hipError_t e = hipSetDevice(device);
         if (e == hipSuccess) e = hipHostMalloc((void**)&slots, 2 * piece, hipHostMallocDefault);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
@@ -486,7 +490,11 @@ static int upload_file(int fd, size_t size, unsigned char* d_text, int device, s
     for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
     work(0);
     for (auto& th : pool) th.join();
-    if (failed) { for (auto& m : errs) if (!m.empty()) { *err = m; break; } return BLU_ERR_IO; }
+    if (failed) {
+        for (auto& m : errs) if (!m.empty()) { *err = m; break; }
+        (void)hipGetLastError();
+        return failed == 1 ? BLU_ERR_IO : BLU_INGEST_FALLBACK;   // (no pinned memory to be had, say: the CPU parser takes the file)
+    }
     return BLU_OK;
 }
 
@@ -577,6 +585,7 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     {
         std::string io;
         rc = upload_file(fd, size, d_text, device, &io);
+        if (rc == BLU_INGEST_FALLBACK) { if (why) *why = "the pinned staging path failed (" + io + ")"; goto done; }
         if (rc != BLU_OK) { set_error("GPU ingest: reading the table failed: %s", io.c_str()); goto done; }
     }
     lap("upload text");
