@@ -18,7 +18,7 @@ EXPORTS = (
 # include/blu_pipeline.h
 PIPELINE_EXPORTS = ("blu_build_consensus_identities", "blu_free_text", "blu_custom_taxon_from_file", "blu_ingest_only",
                     "blu_db_cache_build", "blu_build_consensus_identities_cfg", "blu_ingest_only_on", "blu_last_ingest_path",
-                    "blu_build_consensus_identities_to_file")
+                    "blu_build_consensus_identities_to_file", "blu_ingest_columns_on", "blu_ingest_columns_free")
 
 BLU_UNMATCHED_TAXID = 0xFFFFFFFF
 BLU_NONE_U8, BLU_NONE_U16, BLU_MAR_NEVER_EQUAL = 0xFF, 0xFFFF, 0xFFFE

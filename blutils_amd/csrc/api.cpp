@@ -30,14 +30,22 @@ using namespace blu;
 
 // The stream-kernel kind the handle's last table wanted, as far as the device has reported it (pinned word, read without
 // synchronisation); 0 = classify on the device again: the first calls, and every 64th.
-static uint32_t known_kind(const blu_taxonomy* tax) {
+// The remembered kind belongs to ONE table: it is keyed by the offsets pointer and the query count of the call that
+// classified, so a handle used in turn on tables of different shape (or on the chunks of a staged table) classifies each
+// of them instead of launching the other table's kind.
+static uint32_t known_kind(const blu_taxonomy* tax, const void* seg_off, uint64_t n_queries) {
     // BLU_STREAM_KIND=ring | noring: that build for every table (tests: both builds must give the same records on any table)
     if (const char* env = getenv("BLU_STREAM_KIND")) {
         if (strcmp(env, "ring") == 0) return 1u;
         if (strcmp(env, "noring") == 0) return 2u;
     }
-    const uint64_t call = tax->ws_calls++;
-    if (!tax->ws_kind_host || (call & 63u) == 0) return 0u;
+    const uint64_t call = __atomic_fetch_add(&tax->ws_calls, 1, __ATOMIC_RELAXED);
+    const bool same_table = tax->ws_kind_key_ptr == seg_off && tax->ws_kind_key_n == n_queries;
+    if (!tax->ws_kind_host || (call & 63u) == 0 || !same_table) {
+        if (tax->ws_kind_host) __atomic_store_n(tax->ws_kind_host, 0u, __ATOMIC_RELAXED);   // (until the device reports this table's kind)
+        tax->ws_kind_key_ptr = seg_off; tax->ws_kind_key_n = n_queries;
+        return 0u;
+    }
     return __atomic_load_n(tax->ws_kind_host, __ATOMIC_RELAXED);
 }
 
@@ -82,7 +90,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         HitsDev hd{hits->bitscore, hits->tax_row, hits->pident, hits->pident_milli, hits->packed, hits->align_len, hits->acc_rank, hits->seg_off,
                    hits->n_hits, hits->n_queries};
         return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count,
-                                tax->ws_kind_dev, known_kind(tax));
+                                tax->ws_kind_dev, known_kind(tax, hits->seg_off, hits->n_queries));
     }
 
     // host pointers: stage over PCIe, run, copy the records back (synchronous).  The table goes over in chunks of whole
@@ -184,7 +192,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
                        milli ? (const uint32_t*)st.pid : nullptr, packed ? (const uint32_t*)st.pid : nullptr, (const int32_t*)st.aln,
                        (const uint32_t*)st.acc, (const uint64_t*)st.seg, cr, cq};
             rc = launch_consensus(td, hd, params->strategy, (blu_result*)st.out, st.s, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count,
-                                  tax->ws_kind_dev, known_kind(tax));
+                                  tax->ws_kind_dev, known_kind(tax, st.seg, cq));
             if (rc != BLU_OK) goto done;
             if (n_chunks > 1) HIP_TRY(hipEventRecord(kernels_done, st.s));
             HIP_TRY(hipMemcpyAsync(out + st.q0, st.out, cq * sizeof(blu_result), hipMemcpyDeviceToHost, st.s));

@@ -136,4 +136,6 @@ struct blu_taxonomy {
     mutable uint32_t* ws_kind_host = nullptr;
     mutable uint32_t* ws_kind_dev = nullptr;
     mutable uint64_t ws_calls = 0;
+    mutable const void* ws_kind_key_ptr = nullptr;   // the table the remembered kind belongs to: its offsets pointer and query count
+    mutable uint64_t ws_kind_key_n = 0;
 };

@@ -75,6 +75,9 @@ namespace blu {
 #define BLU_X_SKIP_GATHER false
 #endif
 #endif
+#ifndef BLU_X_EARLY_CODES
+#define BLU_X_EARLY_CODES 0   // timing only: 1 = codes / kthr rows requested with the reference row, shape 0; 2 = a hashed shape
+#endif
 
 // In-kernel stamps (experiment builds only: -DBLU_EXPERIMENTS -DBLU_X_STAMPS): s_memtime at the phase boundaries of the
 // stream kernel, summed per wave and written over the first records of `out` when the wave is done (scripts/stamps.py).
@@ -327,6 +330,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef RECORD_AUX
 #define RECORD_AUX 18  // sc1 | nt
+#endif
+#ifndef BLU_REF_NT
+#define BLU_REF_NT 0   // reference-row loads non-temporal (experiment)
 #endif
 
 // The bit-score stream of a task whose segments are all streamed goes through a per-wave LDS ring, filled by LDS-DMA
@@ -1464,8 +1470,16 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
             const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
             uint4 w[8];
+#if BLU_REF_NT
+            {
+                const u32x4* refv = reinterpret_cast<const u32x4*>(ref);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const u32x4 x = __builtin_nontemporal_load(refv + k); w[k] = make_uint4(x.x, x.y, x.z, x.w); }
+            }
+#else
 #pragma unroll
             for (int k = 0; k < 8; ++k) w[k] = ref4[k];
+#endif
             // Levels shared by the whole group (find_multi_taxa_consensus.rs:137-180): every row agrees with the reference row on
             // exactly the levels all rows of the span [lo, hi] share, and the scan never looks past the shortest lineage.
             // Seen from the reference row r that is the number of levels whose run reaches dl = r - lo rows to the left and
@@ -1501,7 +1515,12 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             const bool agree = single | (d >= minlen);
             if (!agree && d == 0) pack_status(ra, rb, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
             else {
+#if BLU_X_EARLY_CODES
+                const uint32_t x_shape = BLU_X_EARLY_CODES == 1 ? (r_row & 63u) : (r_row * 2654435761u) % 6000u;
+                const uint32_t* codes = t.codes + (uint64_t)x_shape * t.cstride;
+#else
                 const uint32_t* codes = t.codes + (uint64_t)(r_hdr >> 8) * t.cstride;
+#endif
                 const uint4* codes4 = reinterpret_cast<const uint4*>(codes);
                 const uint32_t b = single ? len_ref : (agree ? minlen - 1 : d - 1);
                 const double ident = pid_f64<PID32>((single | agree) ? r_pid : max_pid);   // the one f64 the cutoff tests need
@@ -1512,7 +1531,11 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 uint32_t ident_k = 0;
                 if constexpr (PID32) ident_k = (single | agree) ? r_pid : max_pid;
                 const bool by_k = PID32 && __ballot(ident_k >= BLU_KTHR_NEVER) == 0ull;
+#if BLU_X_EARLY_CODES
+                const uint4* kthr4 = reinterpret_cast<const uint4*>(t.kthr + (uint64_t)x_shape * t.cstride);
+#else
                 const uint4* kthr4 = reinterpret_cast<const uint4*>(t.kthr + (uint64_t)(r_hdr >> 8) * t.cstride);
+#endif
                 // linnaean_ranks.rs:174-212 + build_blast_consensus_identity.rs:67-82
                 uint64_t F = 0, A = 0;
                 uint32_t mar_level = BLU_NONE_U8, nF = 0;

@@ -98,12 +98,13 @@ struct HitTable {
     // still being filled by this thread from the distinct strings the device sent back.  wait_strings() before either
     // is read.
     std::thread strings_thread;
+    bool strings_ok = true;                      // false: the strings thread ran out of memory (read after wait_strings())
     void wait_strings() { if (strings_thread.joinable()) strings_thread.join(); }
     void clear() {
         wait_strings();
         query_names.clear(); accessions.clear();
         seg_off = {}; bitscore = {}; align_len = {}; tax_desc_row = {}; acc_rank = {}; pident = {};
-        unmatched = n_hits = 0; host_columns = true;
+        unmatched = n_hits = 0; host_columns = true; strings_ok = true;
         dev.reset();
     }
     HitTable() = default;

@@ -23,10 +23,13 @@
 //                      query / accession strings come back packed and a background thread turns them into the host
 //                      tables; after the engine, top_rows_kernel compacts the top-score rows of the rendered queries —
 //                      all the writer reads of the table
-// Library primitives (hipcub scan / radix sort) are used for the bookkeeping; the parsing and dictionary kernels are
-// written here.  HBM-bound byte work: no MFMA.
+// The device-wide exclusive scans and the two stable radix sorts of the bookkeeping are rocPRIM's (AMD's own primitives,
+// called directly: no CUB-API layer); block-level sums and scans are the wave-level DPP / LDS code below; the parsing and
+// dictionary kernels are written here.  HBM-bound byte work: no MFMA.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <unistd.h>
 
 #include <algorithm>
@@ -69,6 +72,47 @@ struct DevTaxidMap { const TaxidMap::E* tab; uint64_t mask; };
         else { set_error("GPU ingest: %s failed: %s", #x, hipGetErrorString(e_)); rc = BLU_ERR_HIP; } \
         goto done; } } while (0)
 
+// ---- block-level sum and exclusive scan: 64-wide wavefronts reduce / scan in registers (DPP), the wave totals meet in LDS ----
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {   // inclusive prefix sum over the 64 lanes
+    v += dpp_u32<0x111>(v);                                        // row_shr:1, :2, :4, :8 (zero shifted in): prefix inside each 16-lane row
+    v += dpp_u32<0x112>(v);
+    v += dpp_u32<0x114>(v);
+    v += dpp_u32<0x118>(v);
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
+                   t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const uint32_t r = lane >> 4;
+    return v + (r == 0 ? 0u : (r == 1 ? t0 : (r == 2 ? t0 + t1 : t0 + t1 + t2)));
+}
+// sum over the block in every thread's return value; `wave_sums` = LDS, one word per wave
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* wave_sums) {
+    const uint32_t incl = wave_incl_scan(v);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) total += wave_sums[w];
+    __syncthreads();
+    return total;
+}
+// exclusive prefix of v over the block
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_sums) {
+    const uint32_t incl = wave_incl_scan(v);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) before += (uint32_t)w < wave ? wave_sums[w] : 0u;
+    __syncthreads();
+    return before + incl - v;
+}
+
 // ---- 1. line index ---------------------------------------------------------------------------------------
 constexpr int TILE_THREADS = 256;
 constexpr uint64_t TILE_BYTES = TILE_THREADS * 16;
@@ -88,9 +132,8 @@ __global__ __launch_bounds__(TILE_THREADS) void count_newlines(const uint4* __re
     const uint64_t base = ((uint64_t)blockIdx.x * TILE_THREADS + threadIdx.x) * 16;
     uint32_t c = 0;
     if (base < size) c = __popc(nl_mask16(text[base / 16], base, size));
-    typedef hipcub::BlockReduce<uint32_t, TILE_THREADS> BR;
-    __shared__ typename BR::TempStorage tmp;
-    const uint32_t total = BR(tmp).Sum(c);
+    __shared__ uint32_t wave_sums[TILE_THREADS / 64];
+    const uint32_t total = block_sum<TILE_THREADS>(c, wave_sums);
     if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
 }
 
@@ -99,10 +142,8 @@ __global__ __launch_bounds__(TILE_THREADS) void write_line_starts(const uint4* _
     const uint64_t base = ((uint64_t)blockIdx.x * TILE_THREADS + threadIdx.x) * 16;
     uint32_t m = 0;
     if (base < size) m = nl_mask16(text[base / 16], base, size);
-    typedef hipcub::BlockScan<uint32_t, TILE_THREADS> BS;
-    __shared__ typename BS::TempStorage tmp;
-    uint32_t before = 0;
-    BS(tmp).ExclusiveSum((uint32_t)__popc(m), before);
+    __shared__ uint32_t wave_sums[TILE_THREADS / 64];
+    const uint32_t before = block_excl_scan<TILE_THREADS>((uint32_t)__popc(m), wave_sums);
     uint64_t k = (uint64_t)tile_base[blockIdx.x] + before;
     while (m) {
         const int b = __ffs(m) - 1;
@@ -227,9 +268,8 @@ __global__ __launch_bounds__(256) void parse_rows(const unsigned char* __restric
 __global__ __launch_bounds__(1024) void count_run_heads(const unsigned long long* __restrict__ h, uint32_t n, unsigned long long* __restrict__ count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t head = i < n && (i == 0 || h[i] != h[i - 1]);
-    typedef hipcub::BlockReduce<uint32_t, 1024> BR;
-    __shared__ typename BR::TempStorage tmp;
-    const uint32_t total = BR(tmp).Sum(head);
+    __shared__ uint32_t wave_sums[1024 / 64];
+    const uint32_t total = block_sum<1024>(head, wave_sums);
     if (threadIdx.x == 0 && total) atomicAdd(count, (unsigned long long)total);   // one atomic per 1024 rows
 }
 
@@ -277,9 +317,8 @@ __global__ void dict_insert(const unsigned long long* __restrict__ h, uint32_t n
 __global__ __launch_bounds__(1024) void dict_count(const Slot* __restrict__ tab, uint64_t n_slots, uint32_t* __restrict__ n_keys) {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t used = s < n_slots && tab[s].hash != 0ull;
-    typedef hipcub::BlockReduce<uint32_t, 1024> BR;
-    __shared__ typename BR::TempStorage tmp;
-    const uint32_t c = BR(tmp).Sum(used);
+    __shared__ uint32_t wave_sums[1024 / 64];
+    const uint32_t c = block_sum<1024>(used, wave_sums);
     if (threadIdx.x == 0 && c) atomicAdd(n_keys, c);
 }
 
@@ -564,9 +603,9 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
         hipLaunchKernelGGL(pos_lengths, dim3((n + 256) / 256), dim3(256), 0, 0, d_pos, n, d_len);
         {
             size_t b = 0;
-            HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_len, d_off, (int)(n + 1)));
+            HIPCHK(rocprim::exclusive_scan(nullptr, b, d_len, d_off, 0ull, (size_t)n + 1, rocprim::plus<unsigned long long>()));
             HIPCHK(need_tmp(b));
-            HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, b, d_len, d_off, (int)(n + 1)));
+            HIPCHK(rocprim::exclusive_scan(d_tmp, b, d_len, d_off, 0ull, (size_t)n + 1, rocprim::plus<unsigned long long>()));
         }
         HIPCHK(hipMemcpy(off.data(), d_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
         bytes.resize(off[n]);
@@ -581,7 +620,7 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     // ---- upload + line index
     lap("device start-up");
     HIPCHK(mem.alloc((void**)&d_text, size + 64));
-    HIPCHK(hipMemset(d_text + (size & ~15ull), 0, 64 + (size & 15)));
+    HIPCHK(hipMemset(d_text + size, 0, 64));   // the padding only: the readers' copies run on streams of their own and may not be ordered against this one
     {
         std::string io;
         rc = upload_file(fd, size, d_text, device, &io);
@@ -598,10 +637,10 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     hipLaunchKernelGGL(count_newlines, grid(n_tiles, 1), dim3(TILE_THREADS), 0, 0, (const uint4*)d_text, (uint64_t)size, d_tile);
     {
         size_t b = 0;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_tile, d_tile_base, (int)(n_tiles + 1)));
+        HIPCHK(rocprim::exclusive_scan(nullptr, b, d_tile, d_tile_base, 0u, (size_t)n_tiles + 1, rocprim::plus<uint32_t>()));
         HIPCHK(need_tmp(b));
         HIPCHK(hipMemset(d_tile + n_tiles, 0, 4));
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, b, d_tile, d_tile_base, (int)(n_tiles + 1)));
+        HIPCHK(rocprim::exclusive_scan(d_tmp, b, d_tile, d_tile_base, 0u, (size_t)n_tiles + 1, rocprim::plus<uint32_t>()));
     }
     {
         uint32_t n_newlines = 0;
@@ -656,9 +695,9 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
         HIPCHK(hipMemset(d_counter, 0, 4));
         hipLaunchKernelGGL(dict_finalize, grid(cap), dim3(256), 0, 0, d_qtab, cap, d_text, d_qpos, d_list_row, d_list_slot, d_counter);
         size_t b = 0;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, b, d_list_row, d_list_row2, d_list_slot, d_list_slot2, (int)n_queries));
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, b, d_list_row, d_list_row2, d_list_slot, d_list_slot2, (size_t)n_queries));
         HIPCHK(need_tmp(b));
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, b, d_list_row, d_list_row2, d_list_slot, d_list_slot2, (int)n_queries));
+        HIPCHK(rocprim::radix_sort_pairs(d_tmp, b, d_list_row, d_list_row2, d_list_slot, d_list_slot2, (size_t)n_queries));
         hipLaunchKernelGGL(dict_assign_ids, grid(n_queries), dim3(256), 0, 0, d_qtab, d_list_slot2, (const uint32_t*)nullptr, n_queries);
         HIPCHK(mem.alloc((void**)&d_qid, (size_t)n_rows * 4));
         hipLaunchKernelGGL(dict_lookup, grid(n_rows), dim3(256), 0, 0, d_qh, d_qpos, n_rows, d_qtab, cap - 1, d_text, d_qpos, d_qid, d_flags);
@@ -781,9 +820,9 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
             int bits = 1;
             while ((1ull << bits) < n_queries) ++bits;
             size_t b = 0;
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, b, d_qid, d_qid2, d_perm, d_perm2, (int)n_rows, 0, bits));
+            HIPCHK(rocprim::radix_sort_pairs(nullptr, b, d_qid, d_qid2, d_perm, d_perm2, (size_t)n_rows, 0u, (unsigned)bits));
             HIPCHK(need_tmp(b));
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, b, d_qid, d_qid2, d_perm, d_perm2, (int)n_rows, 0, bits));   // stable
+            HIPCHK(rocprim::radix_sort_pairs(d_tmp, b, d_qid, d_qid2, d_perm, d_perm2, (size_t)n_rows, 0u, (unsigned)bits));   // stable
         }
         HIPCHK(mem.alloc((void**)&d_seg, ((size_t)n_queries + 1) * 8 * 2));
         HIPCHK(hipMemset(d_seg, 0, ((size_t)n_queries + 1) * 8 * 2));
@@ -827,19 +866,25 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
         HitTable* const hp = &ht;
         ht.strings_thread = std::thread([hp, nt, q_bytes = std::move(q_bytes), q_off = std::move(q_off), a_bytes = std::move(a_bytes),
                                          a_off = std::move(a_off), order = std::move(order)]() {
+            std::atomic<bool> oom{false};            // (an exception must not leave a std::thread: the caller checks strings_ok)
             auto work = [&](unsigned t) {
-                const size_t nq = q_off.size() - 1, na = a_off.size() - 1;
-                for (size_t q = nq * t / nt; q < nq * (t + 1) / nt; ++q)
-                    hp->query_names[q].assign(q_bytes.data() + q_off[q], (size_t)(q_off[q + 1] - q_off[q]));
-                for (size_t r = na * t / nt; r < na * (t + 1) / nt; ++r) {
-                    const uint32_t k = order[r];
-                    hp->accessions[r].assign(a_bytes.data() + a_off[k], (size_t)(a_off[k + 1] - a_off[k]));
-                }
+                try {
+                    const size_t nq = q_off.size() - 1, na = a_off.size() - 1;
+                    for (size_t q = nq * t / nt; q < nq * (t + 1) / nt; ++q)
+                        hp->query_names[q].assign(q_bytes.data() + q_off[q], (size_t)(q_off[q + 1] - q_off[q]));
+                    for (size_t r = na * t / nt; r < na * (t + 1) / nt; ++r) {
+                        const uint32_t k = order[r];
+                        hp->accessions[r].assign(a_bytes.data() + a_off[k], (size_t)(a_off[k + 1] - a_off[k]));
+                    }
+                } catch (const std::bad_alloc&) { oom = true; }
             };
-            std::vector<std::thread> pool;
-            for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
-            work(0);
-            for (auto& th : pool) th.join();
+            try {
+                std::vector<std::thread> pool;
+                struct JoinAll { std::vector<std::thread>& p; ~JoinAll() { for (auto& th : p) if (th.joinable()) th.join(); } } join_all{pool};
+                for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
+                work(0);
+            } catch (...) { oom = true; }
+            if (oom) hp->strings_ok = false;
         });
     }
 
@@ -1040,9 +1085,9 @@ int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_
         if (nq) hipLaunchKernelGGL(top_rows_kernel, g, dim3(256), 0, 0, d_out, dev.seg_off, dev.bitscore, nq, d_cnt, nullptr, nullptr, nullptr,
                                    nullptr, nullptr, nullptr, nullptr);
         size_t b = 0;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_cnt, d_cnt + nq + 1, (int)(nq + 1)));
+        HIPCHK(rocprim::exclusive_scan(nullptr, b, d_cnt, d_cnt + nq + 1, 0ull, (size_t)nq + 1, rocprim::plus<unsigned long long>()));
         HIPCHK(hipMalloc(&d_tmp, std::max<size_t>(b, 16)));
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, b, d_cnt, d_cnt + nq + 1, (int)(nq + 1)));
+        HIPCHK(rocprim::exclusive_scan(d_tmp, b, d_cnt, d_cnt + nq + 1, 0ull, (size_t)nq + 1, rocprim::plus<unsigned long long>()));
         top->off.resize(nq + 1);
         HIPCHK(hipMemcpy(top->off.data(), d_cnt + nq + 1, (nq + 1) * 8, hipMemcpyDeviceToHost));
         const uint64_t n_top = top->off[nq];

@@ -368,7 +368,9 @@ int load_db(const char* path, bool use_taxid, Db& db) {
                 if (!j.eat('}')) j.ok = false;
                 if (!j.ok) break;
                 if (!has_taxid || !has_n || !has_t) { set_error("taxonomy entry %zu lacks taxid/numericLineage/textLineage", db.taxid.size()); return BLU_ERR_PARSE; }
-                add_lineage(db, (int64_t)taxid, use_taxid ? numeric : text);   // mod.rs:278 (u64 -> f64 -> i64), :287-291
+                // mod.rs:278 (u64 -> f64 -> i64), :287-291; a value no i64 holds cannot equal any subject_taxid of the Int64 column
+                const int64_t taxid_i = taxid >= 9223372036854775808.0 ? INT64_MAX : (taxid <= -9223372036854775808.0 ? INT64_MIN : (int64_t)taxid);
+                add_lineage(db, taxid_i, use_taxid ? numeric : text);
             } while (j.ok && j.eat(','));
             if (!j.eat(']')) j.ok = false;
         } while (j.ok && j.eat(','));
@@ -422,6 +424,7 @@ bool parse_f64(std::string_view v, double* out) {
     auto r = std::from_chars(b, e, *out);
     if (r.ec == std::errc() && r.ptr == e) return true;
     if ((unsigned char)*b <= ' ') return false;         // (strtod would skip leading blanks; a typed CSV column does not)
+    for (const char* q = b; q < e; ++q) if (*q == 'x' || *q == 'X') return false;   // (nor does it read C's hexadecimal floats)
     std::string tmp(v);
     char* endp = nullptr;
     *out = strtod(tmp.c_str(), &endp);
@@ -436,13 +439,16 @@ bool parse_i64(std::string_view v, int64_t* out) {
     if (p == e) return false;
     const bool neg = *p == '-';
     if (*p == '-' || *p == '+') ++p;
-    if (p == e || e - p > 18) return false;
-    int64_t x = 0;
+    if (p == e) return false;
+    uint64_t x = 0;                                        // the whole i64 range, leading zeros included; beyond it: not an Int64
+    const uint64_t lim = neg ? (1ull << 63) : (1ull << 63) - 1;
     for (; p < e; ++p) {
-        if ((unsigned)(*p - '0') >= 10u) return false;
-        x = x * 10 + (*p - '0');
+        const unsigned d = (unsigned)(*p - '0');
+        if (d >= 10u) return false;
+        if (x > (lim - d) / 10) return false;
+        x = x * 10 + d;
     }
-    *out = neg ? -x : x;
+    *out = neg ? (int64_t)(0 - x) : (int64_t)x;
     return true;
 }
 
@@ -1102,14 +1108,19 @@ unsigned worker_threads() {
 }
 
 // f(k) for k in [0, n), handed out one at a time to `nthreads` workers
+// Returns false if a worker ran out of memory (std::bad_alloc from an output buffer): an exception must not leave a
+// std::thread — that is std::terminate for the whole host process — so it is caught here and the remaining work dropped.
 template <class F>
-void parallel_dynamic(size_t n, unsigned nthreads, F&& f) {
-    if (nthreads <= 1 || n <= 1) { for (size_t k = 0; k < n; ++k) f(k); return; }
+bool parallel_dynamic(size_t n, unsigned nthreads, F&& f) {
+    std::atomic<bool> oom{false};
+    auto guarded = [&](size_t k) { try { f(k); } catch (const std::bad_alloc&) { oom = true; } };
+    if (nthreads <= 1 || n <= 1) { for (size_t k = 0; k < n && !oom; ++k) guarded(k); return !oom; }
     std::atomic<size_t> next{0};
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < nthreads && t < n; ++t)
-        pool.emplace_back([&]() { for (size_t k = next.fetch_add(1); k < n; k = next.fetch_add(1)) f(k); });
+        pool.emplace_back([&]() { for (size_t k = next.fetch_add(1); k < n && !oom.load(std::memory_order_relaxed); k = next.fetch_add(1)) guarded(k); });
     for (auto& th : pool) th.join();
+    return !oom;
 }
 
 // out_path != nullptr: the document is written there (an existing file is replaced, write_blutils_output.rs:57-63) by a
@@ -1162,6 +1173,15 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
 
     t0 = now_s();
     tax_thread.join();
+    if (tax_rc == BLU_ERR_HIP || tax_rc == BLU_ERR_ALLOC) {
+        // the table was built while the ingest held its work buffers (sized from a snapshot of the free memory that did not
+        // know about it): on a nearly full card that can fail where the sequential order would not have — once more, now
+        // that the ingest has handed its buffers back
+        if (tr.on) fprintf(stderr, "[pipeline] taxonomy create failed beside the ingest (%s): once more\n", tax_err.c_str());
+        tax_rc = blu_taxonomy_create(&desc, &params->cutoffs, params->device, &tax);
+        if (tax_rc == BLU_OK) blu_taxonomy_row_map(tax, fwd.data(), nullptr);
+        else { char b[1024]; blu_last_error(b, sizeof b); tax_err = b; }
+    }
     if (tax_rc != BLU_OK) { set_error("%s", tax_err.c_str()); return tax_rc; }
     if (tr.on) fprintf(stderr, "[pipeline] (taxonomy create, 2nd thread %.3f s)\n", t_tax);
     tr.lap("wait for the taxonomy");
@@ -1212,6 +1232,7 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
 
     t0 = now_s();
     ht.wait_strings();
+    if (!ht.strings_ok) { set_error("out of memory while building the query / accession strings"); return BLU_ERR_ALLOC; }
     tr.lap("wait for the strings");
     // results + headers without hits (mod.rs:86-102), sorted by query (write_blutils_output.rs:111)
     struct Item { const std::string* name; int64_t q; };
@@ -1304,10 +1325,15 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
             // write_blutils_output.rs:58-63: an existing file is removed, then a new one created.  (Truncating it in place
             // instead makes ext4 allocate and flush the new blocks inside close().)  The old inode is held open across the
             // unlink, so that dropping its pages happens in close(old) on a thread of its own.
-            const int old = open(out_path, O_RDONLY);
-            if (old >= 0) {
-                if (unlink(out_path) != 0) { close(old); set_error("cannot replace %s", out_path); return BLU_ERR_IO; }
-                old_file = std::thread([old]() { close(old); });
+            // Only a regular file is replaced that way: a FIFO would block in open(O_RDONLY), and a device node
+            // (/dev/stdout, /dev/null) must be written to, not deleted.
+            struct stat sb;
+            if (stat(out_path, &sb) == 0 && S_ISREG(sb.st_mode)) {
+                const int old = open(out_path, O_RDONLY | O_NONBLOCK);
+                if (old >= 0) {
+                    if (unlink(out_path) != 0) { close(old); set_error("cannot replace %s", out_path); return BLU_ERR_IO; }
+                    old_file = std::thread([old]() { close(old); });
+                }
             }
             fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
             if (fd < 0) { set_error("cannot write %s", out_path); return BLU_ERR_IO; }
@@ -1332,9 +1358,23 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
                     pool.push_back(std::move(pieces[k]));
                 }
             });
+        // (should this thread leave by an exception — an allocation of its own failing — the writer is released and joined
+        // first: a joinable std::thread must not be destroyed, and the writer must not wait for pieces that never come)
+        struct WriterGuard {
+            std::thread& w; std::vector<uint8_t>& ready; std::mutex& mu; std::condition_variable& cv; bool& ok;
+            ~WriterGuard() {
+                if (!w.joinable()) return;
+                { std::lock_guard<std::mutex> lk(mu); ok = false; std::fill(ready.begin(), ready.end(), (uint8_t)1); }
+                cv.notify_all();
+                w.join();
+            }
+        } writer_guard{writer, ready, mu, cv, write_ok};
         publish(0);
         std::atomic<uint64_t> cpu_us{0};
+        std::atomic<bool> render_oom{false};   // a worker ran out of memory: its piece and all later ones are published empty (the writer must not wait for them)
         parallel_dynamic(n_blocks, items.size() < 4096 ? 1 : nthreads, [&](size_t bk) {
+            if (render_oom.load(std::memory_order_relaxed)) { publish(bk + 1); return; }
+            try {
             thread_local Renderer::Scratch sc;
             const double tc = thread_cpu_s();
             Out po;
@@ -1359,6 +1399,7 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
             }
             pieces[bk + 1] = std::move(po);
             cpu_us += (uint64_t)((thread_cpu_s() - tc) * 1e6);
+            } catch (const std::bad_alloc&) { render_oom = true; }
             publish(bk + 1);
         });
         Out& tail = pieces.back();
@@ -1372,11 +1413,13 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
             writer.join();
             tr.lap("wait for the writer");
             const bool closed = close(fd) == 0;
+            if (render_oom) { set_error("out of memory while rendering the results"); return BLU_ERR_ALLOC; }
             if (!closed || !write_ok) { set_error("cannot write %s", out_path); return BLU_ERR_IO; }
             document->written = true;
             if (tr.on) fprintf(stderr, "[pipeline] (writer thread: %.3f s inside write())\n", t_write);
             tr.lap("close file");
         }
+        if (render_oom) { set_error("out of memory while rendering the results"); return BLU_ERR_ALLOC; }
     }
     st.t_render_s = now_s() - t0;
     if (stats) *stats = st;
@@ -1402,7 +1445,9 @@ int blu_build_consensus_identities_cfg(const char* blast_output_file, const char
     *out_text = nullptr;
     if (out_len) *out_len = 0;
     Document d;
-    const int rc = build_document(blast_output_file, headers, n_headers, taxonomies_file, params, run_id_text, config_text, nullptr, &d, stats);
+    int rc;
+    try { rc = build_document(blast_output_file, headers, n_headers, taxonomies_file, params, run_id_text, config_text, nullptr, &d, stats); }
+    catch (const std::bad_alloc&) { set_error("out of memory"); return BLU_ERR_ALLOC; }   // (no exception crosses the C ABI)
     if (rc != BLU_OK) return rc;
     const size_t total = d.size();
     char* buf = (char*)malloc(total + 1);
@@ -1423,7 +1468,9 @@ int blu_build_consensus_identities_to_file(const char* blast_output_file, const 
                                            blu_pipeline_stats* stats) {
     if (!out_path) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
     Document d;
-    const int rc = build_document(blast_output_file, headers, n_headers, taxonomies_file, params, run_id_text, config_text, out_path, &d, stats);
+    int rc;
+    try { rc = build_document(blast_output_file, headers, n_headers, taxonomies_file, params, run_id_text, config_text, out_path, &d, stats); }
+    catch (const std::bad_alloc&) { set_error("out of memory"); return BLU_ERR_ALLOC; }
     if (rc != BLU_OK) return rc;
     if (d.written) return BLU_OK;
     // (YAML: one piece, written here) write_blutils_output.rs:57-63: an existing file is replaced
@@ -1471,6 +1518,7 @@ int blu_ingest_only_on(const char* blast_output_file, const char* taxonomies_fil
     st.n_hits = ht.bitscore.size(); st.n_queries = ht.query_names.size(); st.n_taxids = db.taxid.size(); st.n_unmatched_rows = ht.unmatched;
     if (stats) *stats = st;
     ht.wait_strings();
+    if (!ht.strings_ok) { set_error("out of memory while building the query / accession strings"); return BLU_ERR_ALLOC; }
     if (checksum) {
         uint64_t h = 1469598103934665603ull;
         auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
@@ -1482,6 +1530,54 @@ int blu_ingest_only_on(const char* blast_output_file, const char* taxonomies_fil
         *checksum = h;
     }
     return BLU_OK;
+}
+
+int blu_ingest_columns_on(const char* blast_output_file, const char* taxonomies_file, int use_taxid, int device,
+                          blu_ingest_columns* out) {
+    if (!blast_output_file || !taxonomies_file || !out) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    memset(out, 0, sizeof *out);
+    Db db;
+    int rc = load_db(taxonomies_file, use_taxid != 0, db);
+    if (rc != BLU_OK) return rc;
+    HitTable ht;
+    rc = load_hits(blast_output_file, db, ht, device);
+    if (rc != BLU_OK) return rc;
+    ht.wait_strings();
+    if (!ht.strings_ok) { set_error("out of memory while building the query / accession strings"); return BLU_ERR_ALLOC; }
+    const size_t nh = ht.bitscore.size(), nq = ht.query_names.size();
+    auto dup = [](const void* src, size_t bytes) -> void* { void* p = malloc(bytes ? bytes : 1); if (p && bytes) memcpy(p, src, bytes); return p; };
+    auto pack = [](const std::vector<std::string>& v, uint64_t* bytes) -> char* {
+        size_t n = 0;
+        for (auto& s : v) n += s.size() + 1;
+        char* p = (char*)malloc(n ? n : 1);
+        if (!p) return nullptr;
+        size_t at = 0;
+        for (auto& s : v) { memcpy(p + at, s.data(), s.size()); at += s.size(); p[at++] = 0; }
+        *bytes = n;
+        return p;
+    };
+    out->n_hits = nh; out->n_queries = nq; out->n_accessions = ht.accessions.size();
+    out->seg_off = (uint64_t*)dup(ht.seg_off.data(), (nq + 1) * 8);
+    out->bitscore = (int32_t*)dup(ht.bitscore.data(), nh * 4);
+    out->align_len = (int32_t*)dup(ht.align_len.data(), nh * 4);
+    out->tax_desc_row = (uint32_t*)dup(ht.tax_desc_row.data(), nh * 4);
+    out->acc_rank = (uint32_t*)dup(ht.acc_rank.data(), nh * 4);
+    out->pident = (double*)dup(ht.pident.data(), nh * 8);
+    out->query_names = pack(ht.query_names, &out->query_names_bytes);
+    out->accessions = pack(ht.accessions, &out->accessions_bytes);
+    if (!out->seg_off || !out->bitscore || !out->align_len || !out->tax_desc_row || !out->acc_rank || !out->pident || !out->query_names || !out->accessions) {
+        blu_ingest_columns_free(out);
+        set_error("out of memory");
+        return BLU_ERR_ALLOC;
+    }
+    return BLU_OK;
+}
+
+void blu_ingest_columns_free(blu_ingest_columns* c) {
+    if (!c) return;
+    free(c->seg_off); free(c->bitscore); free(c->align_len); free(c->tax_desc_row); free(c->acc_rank); free(c->pident);
+    free(c->query_names); free(c->accessions);
+    memset(c, 0, sizeof *c);
 }
 
 // domain/dtos/taxon.rs:28-66: YAML (flat `key: value` lines) or JSON object with the eight fields

@@ -52,6 +52,38 @@ def ingest_only(blast_output: str, taxonomies_file: str, use_taxid: bool = False
     return {f: getattr(st, f) for f, _ in PipelineStats._fields_}, ck.value
 
 
+class IngestColumns(C.Structure):
+    _fields_ = [("n_hits", C.c_uint64), ("n_queries", C.c_uint64), ("n_accessions", C.c_uint64), ("seg_off", C.POINTER(C.c_uint64)),
+                ("bitscore", C.POINTER(C.c_int32)), ("align_len", C.POINTER(C.c_int32)), ("tax_desc_row", C.POINTER(C.c_uint32)),
+                ("acc_rank", C.POINTER(C.c_uint32)), ("pident", C.POINTER(C.c_double)), ("query_names", C.c_void_p),
+                ("query_names_bytes", C.c_uint64), ("accessions", C.c_void_p), ("accessions_bytes", C.c_uint64)]
+
+
+def ingest_columns(blast_output: str, taxonomies_file: str, use_taxid: bool = False, device: int = -1) -> dict:
+    """The SoA columns of the ingest (include/blu_pipeline.h: blu_ingest_columns_on) as numpy arrays + the two string tables."""
+    import numpy as np
+    L = _bind()
+    L.blu_ingest_columns_on.restype = C.c_int
+    L.blu_ingest_columns_on.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(IngestColumns)]
+    L.blu_ingest_columns_free.argtypes = [C.POINTER(IngestColumns)]
+    c = IngestColumns()
+    rc = L.blu_ingest_columns_on(blast_output.encode(), taxonomies_file.encode(), 1 if use_taxid else 0, device, C.byref(c))
+    if rc != N.BLU_OK:
+        raise N.BluError(rc, "blu_ingest_columns_on")
+    try:
+        nh, nq = int(c.n_hits), int(c.n_queries)
+        arr = lambda p, n, dt: np.ctypeslib.as_array(p, shape=(max(n, 1),))[:n].astype(dt, copy=True)
+        out = {"seg_off": arr(c.seg_off, nq + 1, np.uint64), "bitscore": arr(c.bitscore, nh, np.int32),
+               "align_len": arr(c.align_len, nh, np.int32), "tax_desc_row": arr(c.tax_desc_row, nh, np.uint32),
+               "acc_rank": arr(c.acc_rank, nh, np.uint32), "pident": arr(c.pident, nh, np.float64)}
+        split = lambda p, n: C.string_at(p, n).split(b"\0")[:-1] if n else []
+        out["query_names"] = split(c.query_names, int(c.query_names_bytes))
+        out["accessions"] = split(c.accessions, int(c.accessions_bytes))
+        return out
+    finally:
+        L.blu_ingest_columns_free(C.byref(c))
+
+
 def last_ingest_path() -> str:
     """'gpu' or 'cpu': the parser the last ingest of this thread used."""
     return "gpu" if N.lib().blu_last_ingest_path() == 1 else "cpu"

@@ -90,6 +90,25 @@ int blu_ingest_only(const char* blast_output_file, const char* taxonomies_file, 
 int blu_ingest_only_on(const char* blast_output_file, const char* taxonomies_file, int use_taxid, int device,
                        blu_pipeline_stats* stats, uint64_t* checksum);
 
+/* The columns themselves (what blu_ingest_only[_on] hashes), for a caller that wants the SoA table and for tests that
+ * compare the parsers column by column with an independent reading of the file.  Every array is malloc'd by the library
+ * and released by blu_ingest_columns_free; query_names / accessions are the strings back to back, each NUL-terminated
+ * (queries in first-appearance order, accessions in byte order = acc_rank order). */
+typedef struct blu_ingest_columns {
+    uint64_t n_hits, n_queries, n_accessions;
+    uint64_t* seg_off;        /* [n_queries + 1] */
+    int32_t* bitscore;        /* [n_hits] truncated toward zero (mod.rs:184) */
+    int32_t* align_len;       /* [n_hits] */
+    uint32_t* tax_desc_row;   /* [n_hits] row of the taxonomies file (left join, mod.rs:72-76) or BLU_UNMATCHED_TAXID */
+    uint32_t* acc_rank;       /* [n_hits] */
+    double* pident;           /* [n_hits] */
+    char* query_names; uint64_t query_names_bytes;
+    char* accessions; uint64_t accessions_bytes;
+} blu_ingest_columns;
+int blu_ingest_columns_on(const char* blast_output_file, const char* taxonomies_file, int use_taxid, int device,
+                          blu_ingest_columns* out);
+void blu_ingest_columns_free(blu_ingest_columns* cols);
+
 /* Which parser the calling thread's last ingest used: 0 = CPU, 1 = GPU. */
 int blu_last_ingest_path(void);
 

@@ -148,3 +148,87 @@ def test_garbage_input_is_refused_like_on_the_cpu(tmp_path, force_gpu):
             except N.BluError as e:
                 outcome.append(("error", e.code))
         assert outcome[0] == outcome[1], (name, outcome)
+
+
+# ---- the GPU parser against oracles that share nothing with either product parser ----------------------------------------
+def _assert_columns_equal(got, exp):
+    for k in ("seg_off", "bitscore", "align_len", "tax_desc_row", "acc_rank"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert np.array_equal(got["pident"].view(np.uint64), exp["pident"].view(np.uint64))      # bit for bit
+    assert got["query_names"] == exp["query_names"] and got["accessions"] == exp["accessions"]
+
+
+@pytest.mark.parametrize("eol", ["lf", "crlf", "crlf_no_final_newline"])
+def test_gpu_parser_against_an_independent_reading(tmp_path, force_gpu, eol):
+    """Every numeric spelling the GPU parser takes (tests/test_ingest.py: grammar_rows), columns compared one by one with
+    tests/ingest_reference.py — Python's float() / int() on str.split fields, the reference's schema (mod.rs:226-244)."""
+    from tests import ingest_reference as ref
+    from tests.test_ingest import grammar_db, grammar_rows
+    rows = grammar_rows(True) * 40                    # 1920 rows: several 256-line blocks of the parse kernel
+    sep = "\n" if eol == "lf" else "\r\n"
+    bt = tmp_path / "g.tsv"
+    bt.write_bytes((sep.join(rows) + ("" if eol == "crlf_no_final_newline" else sep)).encode())
+    tj = grammar_db(tmp_path)
+    exp = ref.read_table(str(bt), tj)
+    got = pipeline.ingest_columns(str(bt), tj, device=0)
+    assert pipeline.last_ingest_path() == "gpu"
+    _assert_columns_equal(got, exp)
+    st, ck = pipeline.ingest_only(str(bt), tj, False, device=0)
+    assert pipeline.last_ingest_path() == "gpu" and ck == ref.checksum(exp)
+    assert st["n_unmatched_rows"] == int((exp["tax_desc_row"] == ref.UNMATCHED).sum()) > 0
+
+
+def test_spellings_the_gpu_parser_declines_still_give_the_independent_columns(tmp_path, force_gpu):
+    """A leading '+', 17-digit mantissas, 1e-180: the GPU parser hands the file over, and what comes back is still what
+    Python reads."""
+    from tests import ingest_reference as ref
+    from tests.test_ingest import grammar_db, grammar_rows
+    bt = tmp_path / "g.tsv"
+    bt.write_text("\n".join(grammar_rows(False) * 10) + "\n")
+    tj = grammar_db(tmp_path)
+    got = pipeline.ingest_columns(str(bt), tj, device=0)
+    assert pipeline.last_ingest_path() == "cpu"
+    _assert_columns_equal(got, ref.read_table(str(bt), tj))
+
+
+@pytest.mark.parametrize("layout", ["scrambled", "long_names"])
+def test_gpu_parser_columns_of_blast_shaped_tables(tmp_path, force_gpu, layout):
+    from tests import ingest_reference as ref
+    rng = np.random.default_rng(15)
+    rows = _rows(3000, 9, rng, long_names=layout == "long_names")
+    if layout == "scrambled":
+        order = sorted(range(len(rows)), key=lambda i: (int(rng.integers(0, 5)), i))
+        rows = [rows[i] for i in order]
+    bt = tmp_path / "b.tsv"
+    bt.write_text("\n".join(rows) + "\n")
+    tj = _db(tmp_path)
+    got = pipeline.ingest_columns(str(bt), tj, device=0)
+    assert pipeline.last_ingest_path() == "gpu"
+    _assert_columns_equal(got, ref.read_table(str(bt), tj))
+
+
+@pytest.mark.parametrize("strategy,use_taxid", [("relaxed", False), ("cautious", True)])
+def test_gpu_parsed_c1_files_give_the_faithful_oracles_document(tmp_path, golden_dir, force_gpu, strategy, use_taxid):
+    """BASELINE config 1 as files, the table parsed by the GPU (forced: it is under 1 MiB), every rendered field compared
+    with the string-faithful oracle fed from an independent Python reading of the same two files."""
+    from blutils_amd import synth
+    from oracle import oracle as orc
+    from tests.test_gpu_pipeline import _oracle_from_files, _write_inputs
+    tax = synth.make_taxonomy(2000, synth.SEEDS["C1"])
+    hits = synth.make_hits(tax, 1000, synth.SEEDS["C1"], 10, p_unmatched=0.002).numpy()
+    bt, tj, _ = _write_inputs(tmp_path, tax, hits, use_taxid)
+    vals = json.load(open(os.path.join(golden_dir, "custom_taxon_cutoffs_bacteria_16S.json")))["values"]
+    custom = {k: v for k, v in vals.items() if v is not None}
+    got, stats = pipeline.build_consensus_identities(bt, tj, "custom", strategy, use_taxid, custom, lenient=True)
+    assert pipeline.last_ingest_path() == "gpu"
+    assert stats["n_queries"] == 1000 and stats["n_hits"] == 10000
+    exp = _oracle_from_files(bt, tj, use_taxid, "custom", strategy, custom)
+    n_found = 0
+    for g in got:
+        o = exp[g["query"]]
+        if o["status"] != orc.ST_CONSENSUS:
+            assert g["taxon"] is None, g["query"]
+            continue
+        n_found += 1
+        assert g["taxon"] == o["taxon"], (g["query"], g["taxon"], o["taxon"])
+    assert n_found > 900

@@ -66,3 +66,65 @@ def test_ingest_errors(tmp_path):
     notnum.write_text("q1\tA.1\tabc\t99.0\t400\t0\t0\t1\t400\t1\t400\t1e-50\t700\n")
     with pytest.raises(N.BluError):
         pipeline.ingest_only(str(notnum), tj)
+
+
+# ---- the product parsers against an independent reading (tests/ingest_reference.py: str.split, float(), int()) ----------
+def grammar_rows(gpu_forms_only: bool):
+    """Rows whose numeric fields use every spelling the strict grammar admits.  gpu_forms_only: leave out the spellings the
+    GPU parser hands to the CPU one (a leading '+', more than 15 significant digits, |exponent| beyond the one-operation
+    fast path)."""
+    pid_forms = ["99.356", "100", "100.000", "7e1", "9.9356e+01", "099.5", "97.", ".5e2", "8.05E1", "0.0", "-0.0", "66.667"]
+    bs_forms = ["845", "845.0", "56.5", "7e2", "1E3", "0.5", "-0.0", "-3.7", "1.148e+05", "2147483647", "-2147483648.9", "1999.999"]
+    tax_forms = ["105", "0105", "00000105", "-5", "999999999999", "100", "3099", "3100", "0", "-0", "101", "102"]
+    aln_forms = ["400", "0400", "0", "-12", "2147483647", "-2147483648", "1", "38", "00038", "1500", "7", "9"]
+    if not gpu_forms_only:
+        pid_forms += ["+99.5", "99.123456789012345678", "1e-180", "1.7976931348623157e308", "0.000000000000000000001e23", "12345678901234567e-15"]
+        bs_forms += ["+7", "7.00000000000000000001", "1e-180", "123456789.12345678", "1e9", "+0.0"]
+        tax_forms += ["+105", "+0", "9223372036854775807", "-9223372036854775808", "000000000000000000000105", "+3099"]
+        aln_forms += ["+400", "+0", "000000000000000000000400", "+1", "-0", "+2147483647"]
+    rows = []
+    n = len(pid_forms)
+    for i in range(4 * n):
+        q = f"query{i // 3:04d}"                              # three rows per query, rows of a query not always adjacent
+        acc = ["NR_000105.1", "a_much_longer_accession_string_00000105.12", "NR_000105.10", "NR_000105", "B"][i % 5]
+        dead = ["1\t0\t1\t400\t1\t400\t1e-50", "\t\t\t\t\t\t", "x\ty\tz\t-\t \tNaN\tinf"][i % 3]   # the dead columns are never parsed
+        rows.append(f"{q}\t{acc}\t{tax_forms[i % n]}\t{pid_forms[(i * 5 + 1) % n]}\t{aln_forms[(i * 7 + 2) % n]}\t{dead}\t{bs_forms[(i * 11 + 3) % n]}")
+    return rows
+
+
+def grammar_db(tmp_path):
+    tj = tmp_path / "g.json"
+    tj.write_text(json.dumps({"blutilsVersion": "x", "sourceDatabase": "y", "taxonomies": [
+        {"taxid": t, "rank": "species", "numericLineage": f"d__2;g__{t // 7};s__{t}",
+         "textLineage": f"d__b;g__g{t // 7};s__s{t}", "accessions": []} for t in list(range(100, 3100)) + [0, 999999999999]]}))   # (taxid is a u64 in the DB: taxonomies_map.rs)
+    return str(tj)
+
+
+@pytest.mark.parametrize("eol", ["lf", "crlf", "crlf_no_final_newline"])
+def test_cpu_parser_against_an_independent_reading(tmp_path, eol):
+    from tests import ingest_reference as ref
+    rows = grammar_rows(False)
+    sep = "\n" if eol == "lf" else "\r\n"
+    bt = tmp_path / "g.tsv"
+    bt.write_bytes((sep.join(rows) + ("" if eol == "crlf_no_final_newline" else sep)).encode())
+    tj = grammar_db(tmp_path)
+    exp = ref.read_table(str(bt), tj)
+    st, ck = pipeline.ingest_only(str(bt), tj, device=-1)
+    assert st["n_hits"] == len(rows) and st["n_queries"] == len(exp["query_names"])
+    assert st["n_unmatched_rows"] == int((exp["tax_desc_row"] == ref.UNMATCHED).sum()) > 0
+    assert ck == ref.checksum(exp)
+
+
+def test_int64_columns_take_no_fraction_and_floats_no_junk(tmp_path):
+    """mod.rs:226-244: subject_taxid and align_length are Int64 (a fraction, an exponent or a blank fails the file as it
+    fails the reference's typed CSV reader); a float field is a number from its first to its last byte."""
+    tj = grammar_db(tmp_path)
+    good = "q1\tA.1\t100\t99.0\t400\t0\t0\t1\t400\t1\t400\t1e-50\t700"
+    for col, value in ((2, "100.0"), (2, "1e2"), (2, ""), (2, " 100"), (4, "400."), (4, "4e2"), (4, ""), (3, "99.0x"), (3, " 99.0"),
+                       (3, ""), (3, "1_0"), (3, "0x10"), (12, "700 "), (12, ""), (12, "--7"), (12, "7e"), (12, "e7"), (12, ".")):
+        c = good.split("\t")
+        c[col] = value
+        f = tmp_path / "strict.tsv"
+        f.write_text(good + "\n" + "\t".join(c) + "\n")
+        with pytest.raises(N.BluError, match="numeric"):
+            pipeline.ingest_only(str(f), tj, device=-1)
