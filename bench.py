@@ -41,6 +41,7 @@ KERNEL_SOURCES = ("blutils_amd/csrc/consensus_kernel.hip", "blutils_amd/csrc/blu
 
 
 LAYOUT_TEXT = {"packed": "bit-score column + 16-byte side records, perc_identity as milli-percent u32 (lossless, 20 B/hit)",
+               "packed64": "bit-score column + 24-byte side records with perc_identity as f64 (28 B/hit)",
                "milli": "five columns, perc_identity as milli-percent u32 (lossless, 20 B/hit)",
                "f64": "five columns, perc_identity as f64 (24 B/hit)"}
 
@@ -80,6 +81,125 @@ def count_top_rows(hits) -> int:
     return total
 
 
+def useful_bytes(pident: str, n_hits: int, n_queries: int, top_rows: int) -> int:
+    """Bytes the reference semantics need from a table in this layout: every bit-score, the other values of the top-score
+    rows only (16 B in the milli-percent layouts, 20 B with an f64 column, 24 B as f64 side records), offsets, records."""
+    side = {"f64": 20, "packed64": 24}.get(pident, 16)
+    return 4 * n_hits + side * top_rows + 8 * (n_queries + 1) + 32 * n_queries
+
+
+def build_hit_table(synth, engine, torch, tax, eng_tax, cfg, seed, n_queries, q_offset, top_group, pident, dev, sample):
+    """Synthetic table of `n_queries` queries resident on `dev` in layout `pident`, joined with the taxonomy
+    (desc row -> engine row id: the left join of mod.rs:72-76, done once at ingest).  Returns (hits, device dict the
+    engine reads, the five columns, desc rows of the first `sample` queries for the oracle legs, seconds spent generating)."""
+    f64_cols = pident in ("f64", "packed64")
+    t0 = time.time()
+    hits = synth.make_hits(tax, n_queries, seed, cfg["hits_per_query"], zipf=cfg["zipf"], device=dev, q_offset=q_offset,
+                           columns="f64" if f64_cols else "milli", top_group=top_group)
+    torch.cuda.synchronize()
+    t_hits = time.time() - t0
+    hd = hits.as_dict("f64" if f64_cols else "milli")
+    S_keep = min(hits.n_queries, max(sample, 1))
+    desc_rows_sample = hd["tax_row"][: int(hits.seg_off[S_keep].item())].cpu().numpy()
+    for a in range(0, hits.n_hits, 1 << 26):
+        b = min(hits.n_hits, a + (1 << 26))
+        hd["tax_row"][a:b] = eng_tax.engine_rows(hd["tax_row"][a:b])
+    cols = hd            # the five columns (kept for the oracle sample)
+    if pident in ("packed", "packed64"):
+        hits.tax_row = hd["tax_row"]
+        hd = hits.as_dict(pident, tax=eng_tax)     # blu_hits_pack / blu_hits_pack64: the side records, with the shape hints
+    return hits, hd, cols, desc_rows_sample, t_hits
+
+
+def oracle_sample(np, hits, cols, desc_rows_sample, S, f64_cols):
+    """The first S queries of the table as the numpy columns the oracles read."""
+    seg = hits.seg_off[: S + 1].cpu().numpy()
+    nrow = int(seg[-1])
+    samp = {k: v[:nrow].cpu().numpy() for k, v in cols.items() if k not in ("seg_off", "tax_row")}
+    samp["tax_row"] = desc_rows_sample[:nrow]
+    if not f64_cols:   # the oracle reads the f64 the reference's parser would produce: k / 1000, correctly rounded
+        samp["pident"] = samp.pop("pident_milli").astype(np.float64) / 1000.0
+    return seg, nrow, samp
+
+
+# Workloads measured after the headline in the same run (N = 1): what DESIGN's table quotes, on the driver's box.
+SECONDARY = (
+    dict(name="C3, top groups as in the reference's real output (zymo-mock histogram, mean 5.7 rows)", config="C3", top_group="zymo", pident="packed"),
+    dict(name="C3 shape, all 50 hits of every query tied (table read in full), 2 M queries", config="C3", top_group="all", queries=2000000, pident="packed"),
+    dict(name="C3 in the canonical f64 layout (five columns, 24 B/hit)", config="C3", pident="f64"),
+    dict(name="C3 with f64 side records (blu_hits_pack64, 28 B/hit)", config="C3", pident="packed64"),
+    dict(name="C4 slice: one eighth of C3 (1.25 M queries), what one rank of the 8-GPU run holds", config="C3", queries=1250000, pident="packed"),
+    dict(name="C5: 1 M queries, Zipf 1..5000 hits, deep lineages", config="C5", pident="packed"),
+    dict(name="C2: 100 k queries x 50 hits, 50 k taxids, replayed from a HIP graph", config="C2", pident="packed", graph=True),
+)
+
+
+def run_secondary(args, synth, engine, torch, np, dev, local_rank, custom, reuse):
+    """One entry per SECONDARY workload: kernel_ms (HIP events on the launch stream, mean of `steps`), ms_per_step (wall),
+    value (Mq/s by the wall clock), useful bytes and the roofline fraction they give; a 20 000-query parity gate each."""
+    out_list = []
+    tax_cache = dict(reuse)                      # config name -> (tax, eng_tax)
+    for w in SECONDARY:
+        t_begin = time.time()
+        cfg = dict(synth.CONFIGS[w["config"]])
+        seed = synth.SEEDS[w["config"]]
+        if w["config"] not in tax_cache:
+            tx = synth.make_taxonomy(cfg["n_taxa"], seed, deep=cfg["deep"])
+            tax_cache[w["config"]] = (tx, engine.Taxonomy(tx.lin_off, tx.lin_node, tx.lin_rank, tx.rank_names, taxon=args.taxon,
+                                                          custom=custom, device=local_rank))
+        tax, eng_tax = tax_cache[w["config"]]
+        nq = w.get("queries", cfg["n_queries"])
+        S = min(nq, 20000)
+        hits, hd, cols, desc, _ = build_hit_table(synth, engine, torch, tax, eng_tax, cfg, seed, nq, 0, w.get("top_group", "geo"),
+                                                  w["pident"], dev, S)
+        out = torch.zeros(32 * hits.n_queries, dtype=torch.uint8, device=dev)
+        step = lambda: engine.run_consensus_device(eng_tax, hd, out, strategy=args.strategy)
+        entry = {"workload": w["name"], "config": w["config"], "pident_layout": w["pident"], "queries": hits.n_queries, "hit_rows": hits.n_hits}
+        if not args.no_parity_gate:
+            from oracle import oracle as orc
+            step()
+            torch.cuda.synchronize()
+            seg, nrow, samp = oracle_sample(np, hits, cols, desc, S, w["pident"] in ("f64", "packed64"))
+            exp = orc.columnar_run(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, seg, samp["bitscore"], samp["tax_row"],
+                                   samp["pident"], samp["align_len"], samp["acc_rank"], taxon=args.taxon, strategy=args.strategy,
+                                   custom=custom, threads=CPU_THREADS_CAP)
+            if engine.records_from_tensor(out[: 32 * S]).tobytes() != exp.tobytes():
+                raise SystemExit(f"parity gate FAILED on the secondary workload {w['name']!r}")
+            entry["parity_gate_queries"] = S
+        fn = step
+        if w.get("graph"):
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                step()
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                step()
+            fn = graph.replay
+        for _ in range(min(args.warmup, 3)):
+            fn()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        T_top = count_top_rows(hits)
+        useful = useful_bytes(w["pident"], hits.n_hits, hits.n_queries, T_top)
+        entry.update({"kernel_ms": k_ms, "ms_per_step": wall * 1e3 / args.steps, "value": hits.n_queries * args.steps / wall / 1e6,
+                      "unit": "Mqueries/s", "useful_bytes": useful, "top_rows": T_top,
+                      "achieved": useful / (k_ms * 1e-3) / 1e9, "frac": useful / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                      "seconds": None})
+        del hits, hd, cols, out
+        torch.cuda.empty_cache()
+        entry["seconds"] = round(time.time() - t_begin, 1)
+        log(f"[bench] secondary: {w['name']}: {entry['kernel_ms']:.4f} ms, {entry['value']:.0f} Mq/s, frac {entry['frac']:.3f} ({entry['seconds']} s)")
+        out_list.append(entry)
+    return out_list
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,16 +218,19 @@ def main():
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="auto: strong for N > 1 (BASELINE config 4: ONE table sharded over the ranks), with the weak figure as a "
                          "secondary field; weak: every rank holds a full table of its own")
-    ap.add_argument("--pident", default="packed", choices=["packed", "milli", "f64"],
+    ap.add_argument("--pident", default="packed", choices=["packed", "milli", "f64", "packed64"],
                     help="hit-table layout: packed = bit-score column + 16-byte side records {tax_row, pident_milli, "
                          "align_len, acc_rank} (20 B/hit; a top row's values sit in one memory line); milli = five "
                          "columns with perc_identity as milli-percent u32 (20 B/hit); f64 = five columns with "
-                         "perc_identity as f64 (24 B/hit, the canonical layout of BASELINE.md)")
+                         "perc_identity as f64 (24 B/hit, the canonical layout of BASELINE.md); packed64 = bit-score column + "
+                         "24-byte side records {tax_row, hint, align_len, acc_rank, pident f64} (28 B/hit: any f64 identity, a "
+                         "top row's values in one or two memory lines instead of five)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one run (both kernels) in a HIP graph and time replays: for launch-bound sizes (C2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary weak-scaling measurement of an N > 1 run")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (N = 1: the other workloads of SECONDARY; N > 1: the weak-scaling figure)")
     args = ap.parse_args()
 
     import numpy as np
@@ -165,6 +288,8 @@ def main():
                               custom=custom, device=local_rank)
     t_up = time.time() - t0
 
+    f64_cols = args.pident in ("f64", "packed64")   # layouts whose perc_identity is an f64
+
     def query_range(mode):
         """[q0, q1) of this rank in the global query numbering."""
         if mode == "weak" or world == 1:
@@ -177,23 +302,8 @@ def main():
 
     def build_table(mode):
         q0, q1 = query_range(mode)
-        t0 = time.time()
-        hits = synth.make_hits(tax, q1 - q0, seed, cfg["hits_per_query"], zipf=cfg["zipf"], device=dev, q_offset=q0,
-                               columns="f64" if args.pident == "f64" else "milli", top_group=args.top_group)
-        torch.cuda.synchronize()
-        t_hits = time.time() - t0
-        hd = hits.as_dict("f64" if args.pident == "f64" else "milli")
-        # the join of the hit table with the taxonomy (mod.rs:72-76): desc row -> engine row id, done once at ingest.
-        # The oracle legs read the desc rows of the sampled prefix, kept aside.
-        S_keep = min(hits.n_queries, max(args.cpu_sample, 1))
-        desc_rows_sample = hd["tax_row"][: int(hits.seg_off[S_keep].item())].cpu().numpy()
-        for a in range(0, hits.n_hits, 1 << 26):
-            b = min(hits.n_hits, a + (1 << 26))
-            hd["tax_row"][a:b] = eng_tax.engine_rows(hd["tax_row"][a:b])
-        cols = hd            # the five columns (kept for the oracle sample below)
-        if args.pident == "packed":
-            hits.tax_row = hd["tax_row"]
-            hd = hits.as_dict("packed")
+        hits, hd, cols, desc_rows_sample, t_hits = build_hit_table(synth, engine, torch, tax, eng_tax, cfg, seed, q1 - q0, q0, args.top_group,
+                                                                   args.pident, dev, args.cpu_sample)
         out = torch.zeros(32 * hits.n_queries, dtype=torch.uint8, device=dev)
         return hits, hd, cols, desc_rows_sample, out, t_hits
 
@@ -216,12 +326,7 @@ def main():
         step()
         torch.cuda.synchronize()
         S = min(Q, max(args.cpu_sample, 1))
-        seg = hits.seg_off[: S + 1].cpu().numpy()
-        nrow = int(seg[-1])
-        samp = {k: v[:nrow].cpu().numpy() for k, v in cols.items() if k not in ("seg_off", "tax_row")}
-        samp["tax_row"] = desc_rows_sample[:nrow]
-        if args.pident != "f64":   # the oracle reads the f64 the reference's parser would produce: k / 1000, correctly rounded
-            samp["pident"] = samp.pop("pident_milli").astype(np.float64) / 1000.0
+        seg, nrow, samp = oracle_sample(np, hits, cols, desc_rows_sample, S, f64_cols)
         got = engine.records_from_tensor(out[: 32 * S])
         exp = orc.columnar_run(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, seg, samp["bitscore"],
                                samp["tax_row"], samp["pident"], samp["align_len"], samp["acc_rank"],
@@ -308,13 +413,24 @@ def main():
                      "ms_per_step": e2 * 1e3 / args.steps, "queries_per_gpu": hits2.n_queries,
                      "note": "every rank holds a full table of its own (per-GPU work fixed as N grows)"}
 
+    # ---- secondary workloads of a default N = 1 run (the headline's numbers are final by now: the table is released first)
+    other_workloads = None
+    default_run = not (args.queries or args.taxa or args.hits_per_query or args.graph) and args.top_group == "geo" and args.config == "C3" \
+        and args.pident == "packed" and not distributed
+    if default_run and not args.no_secondary:
+        del hd, cols, out
+        state["hd"] = state["out"] = None
+        hits = None
+        torch.cuda.empty_cache()
+        other_workloads = run_secondary(args, synth, engine, torch, np, dev, local_rank, custom, {"C3": (tax, eng_tax)})
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = total_q * args.steps / elapsed / 1e6
         k_ms = float(np.mean(kernel_ms))
-        row_bytes = 24 if args.pident == "f64" else 20
+        row_bytes = {"f64": 24, "packed64": 28}.get(args.pident, 20)
         alg_bytes = row_bytes * Hn + 8 * (Q + 1) + 32 * Q
-        useful = 4 * Hn + (row_bytes - 4) * T_top + 8 * (Q + 1) + 32 * Q
+        useful = useful_bytes(args.pident, Hn, Q, T_top)
         gbps = lambda b: b / (k_ms * 1e-3) / 1e9
         traffic, traffic_note = None, None
         default_workload = not (args.queries or args.taxa or args.hits_per_query) and args.top_group == "geo" and world == 1
@@ -367,6 +483,8 @@ def main():
         }
         if secondary:
             line["weak_scaling"] = secondary
+        if other_workloads is not None:
+            line["secondary"] = other_workloads
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

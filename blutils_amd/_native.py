@@ -13,7 +13,7 @@ EXPORTS = (
     "blu_abi_version", "blu_last_error", "blu_consensus_run_multi", "blu_shard_ranges", "blu_taxonomy_create", "blu_taxonomy_destroy", "blu_taxonomy_n_tax",
     "blu_taxonomy_n_shapes", "blu_taxonomy_n_rank_codes", "blu_taxonomy_max_depth", "blu_taxonomy_device_bytes",
     "blu_taxonomy_rank_name", "blu_taxonomy_row_cutoffs", "blu_taxonomy_lookup", "blu_taxonomy_row_map", "blu_consensus_run",
-    "blu_consensus_last_launch",
+    "blu_consensus_last_launch", "blu_hits_pack", "blu_hits_pack64",
 )
 # include/blu_pipeline.h
 PIPELINE_EXPORTS = ("blu_build_consensus_identities", "blu_free_text", "blu_custom_taxon_from_file", "blu_ingest_only",
@@ -44,7 +44,8 @@ class TaxonomyDesc(C.Structure):
 class Hits(C.Structure):
     _fields_ = [("bitscore", C.c_void_p), ("tax_row", C.c_void_p), ("pident", C.c_void_p), ("align_len", C.c_void_p),
                 ("acc_rank", C.c_void_p), ("seg_off", C.c_void_p), ("n_hits", C.c_uint64), ("n_queries", C.c_uint64),
-                ("on_device", C.c_int32), ("reserved", C.c_int32), ("pident_milli", C.c_void_p), ("packed", C.c_void_p)]
+                ("on_device", C.c_int32), ("reserved", C.c_int32), ("pident_milli", C.c_void_p), ("packed", C.c_void_p),
+                ("packed64", C.c_void_p)]
 
 
 class RunParams(C.Structure):
@@ -89,6 +90,9 @@ def lib() -> C.CDLL:
     L.blu_taxonomy_row_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.blu_consensus_run.restype = C.c_int
     L.blu_consensus_run.argtypes = [C.c_void_p, C.POINTER(Hits), C.POINTER(RunParams), C.c_void_p]
+    for name in ("blu_hits_pack", "blu_hits_pack64"):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [C.c_void_p, C.POINTER(Hits), C.c_void_p, C.c_void_p]
     L.blu_consensus_last_launch.restype = C.c_int
     L.blu_consensus_last_launch.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     _lib = L

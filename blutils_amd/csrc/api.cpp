@@ -59,16 +59,17 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     if (hits->n_hits >= 0xFFFFFFFFull) { set_error("n_hits must be < 2^32 - 1 per call"); return BLU_ERR_INVALID_ARG; }
     if (hits->n_queries == 0) return BLU_OK;
     if (!out || !hits->seg_off) { set_error("null output or seg_off"); return BLU_ERR_INVALID_ARG; }
-    if (hits->n_hits && (!hits->bitscore || (!hits->packed && (!hits->tax_row || !hits->align_len || !hits->acc_rank)))) {
+    if (hits->n_hits && (!hits->bitscore || (!hits->packed && !hits->packed64 && (!hits->tax_row || !hits->align_len || !hits->acc_rank)))) {
         set_error("null hit column"); return BLU_ERR_INVALID_ARG;
     }
-    if (hits->n_hits && ((hits->pident != nullptr) + (hits->pident_milli != nullptr) + (hits->packed != nullptr) != 1)) {
-        set_error("exactly one of pident / pident_milli / packed must be given"); return BLU_ERR_INVALID_ARG;
+    if (hits->n_hits && ((hits->pident != nullptr) + (hits->pident_milli != nullptr) + (hits->packed != nullptr) + (hits->packed64 != nullptr) != 1)) {
+        set_error("exactly one of pident / pident_milli / packed / packed64 must be given"); return BLU_ERR_INVALID_ARG;
     }
     if (hits->packed && ((uintptr_t)hits->packed & 15u)) { set_error("packed records must be 16-byte aligned"); return BLU_ERR_INVALID_ARG; }
+    if (hits->packed64 && ((uintptr_t)hits->packed64 & 7u)) { set_error("packed64 records must be 8-byte aligned"); return BLU_ERR_INVALID_ARG; }
     if (hipSetDevice(tax->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", tax->device); return BLU_ERR_NO_DEVICE; }
 
-    TaxDev td{tax->d_lin, tax->d_codes, tax->d_kthr, tax->sc, tax->d_lcp8, tax->d_rmq, tax->rmq_nb, tax->d_cutvals, tax->n_cutvals, tax->n_tax, tax->dev_stride, tax->node_base, tax->max_depth};
+    TaxDev td{tax->d_lin, tax->d_codes, tax->d_kthr, tax->sc, tax->d_lcp8, tax->d_rmq, tax->rmq_nb, tax->d_cutvals, tax->n_cutvals, tax->n_tax, tax->dev_stride, tax->node_base, tax->max_depth, std::max<uint32_t>(tax->n_shapes, 1u)};
     if (tax->ws_capacity < hits->n_queries || !tax->ws_count) {
         // grows only when a larger table than any before arrives (first call): not graph-capturable
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
@@ -88,7 +89,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     }
     if (hits->on_device) {
         HitsDev hd{hits->bitscore, hits->tax_row, hits->pident, hits->pident_milli, hits->packed, hits->align_len, hits->acc_rank, hits->seg_off,
-                   hits->n_hits, hits->n_queries};
+                   hits->n_hits, hits->n_queries, hits->packed64};
         return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count,
                                 tax->ws_kind_dev, known_kind(tax, hits->seg_off, hits->n_queries));
     }
@@ -98,8 +99,8 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     // handle's worklist is shared, so the kernels themselves are chained by an event).  A table that fits is one chunk.
     int rc = BLU_OK;
     const size_t nh = hits->n_hits, nq = hits->n_queries;
-    const bool milli = hits->pident_milli != nullptr, packed = hits->packed != nullptr;
-    const size_t row_bytes = (milli || packed) ? 20 : 24;
+    const bool milli = hits->pident_milli != nullptr, packed = hits->packed != nullptr, wide = hits->packed64 != nullptr;
+    const size_t row_bytes = wide ? 28 : ((milli || packed) ? 20 : 24);
     size_t chunk_rows = nh;
     {
         size_t free_b = 0, total_b = 0;
@@ -149,6 +150,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
             Set& st = sets[k];
             HIP_TRY(hipMalloc(&st.bs, max_rows * 4 + pad));
             if (packed) HIP_TRY(hipMalloc(&st.pid, max_rows * 16 + pad));   // the 16-byte records
+            else if (wide) HIP_TRY(hipMalloc(&st.pid, max_rows * 24 + pad));   // the 24-byte records
             else {
                 HIP_TRY(hipMalloc(&st.tax, max_rows * 4 + pad));
                 HIP_TRY(hipMalloc(&st.pid, max_rows * (milli ? 4 : 8) + pad));
@@ -178,6 +180,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
             if (cr) {
                 HIP_TRY(hipMemcpyAsync(st.bs, hits->bitscore + st.r0, cr * 4, hipMemcpyHostToDevice, st.s));
                 if (packed) HIP_TRY(hipMemcpyAsync(st.pid, hits->packed + 4 * st.r0, cr * 16, hipMemcpyHostToDevice, st.s));
+                else if (wide) HIP_TRY(hipMemcpyAsync(st.pid, hits->packed64 + 6 * st.r0, cr * 24, hipMemcpyHostToDevice, st.s));
                 else {
                     HIP_TRY(hipMemcpyAsync(st.tax, hits->tax_row + st.r0, cr * 4, hipMemcpyHostToDevice, st.s));
                     if (milli) HIP_TRY(hipMemcpyAsync(st.pid, hits->pident_milli + st.r0, cr * 4, hipMemcpyHostToDevice, st.s));
@@ -188,9 +191,9 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
             }
             HIP_TRY(hipMemcpyAsync(st.seg, seg_src, (cq + 1) * 8, hipMemcpyHostToDevice, st.s));
             if (n_chunks > 1 && c > 0) HIP_TRY(hipStreamWaitEvent(st.s, kernels_done, 0));   // the previous chunk's kernels own the worklist
-            HitsDev hd{(const int32_t*)st.bs, (const uint32_t*)st.tax, (milli || packed) ? nullptr : (const double*)st.pid,
+            HitsDev hd{(const int32_t*)st.bs, (const uint32_t*)st.tax, (milli || packed || wide) ? nullptr : (const double*)st.pid,
                        milli ? (const uint32_t*)st.pid : nullptr, packed ? (const uint32_t*)st.pid : nullptr, (const int32_t*)st.aln,
-                       (const uint32_t*)st.acc, (const uint64_t*)st.seg, cr, cq};
+                       (const uint32_t*)st.acc, (const uint64_t*)st.seg, cr, cq, wide ? (const uint32_t*)st.pid : nullptr};
             rc = launch_consensus(td, hd, params->strategy, (blu_result*)st.out, st.s, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count,
                                   tax->ws_kind_dev, known_kind(tax, st.seg, cq));
             if (rc != BLU_OK) goto done;
@@ -263,6 +266,7 @@ int blu_consensus_run_multi(const blu_taxonomy* const* taxes, uint32_t n, const 
             h.pident = hits->pident ? hits->pident + r0 : nullptr;
             h.pident_milli = hits->pident_milli ? hits->pident_milli + r0 : nullptr;
             h.packed = hits->packed ? hits->packed + 4 * r0 : nullptr;
+            h.packed64 = hits->packed64 ? hits->packed64 + 6 * r0 : nullptr;
             h.seg_off = seg.data(); h.n_hits = r1 - r0; h.n_queries = q1 - q0;
             blu_run_params p = *params;
             p.stream = nullptr;                                                          // each shard on its device's null stream

@@ -44,6 +44,8 @@ struct TaxDev {
     const uint32_t* codes;   // [n_shapes][cstride]
     const uint32_t* kthr;    // [n_shapes][cstride] per level: smallest milli-percent identity k with fl(k / 1000) >= cutoff (17 bits,
                              // BLU_KTHR_NEVER if none below it) | (fl(that k / 1000) == cutoff) << 17: `>=` and `>` as integer compares
+                             // | canonical rank code << BLU_LVL_RANK_SHIFT | (max-allowed-rank code is BLU_MAR_NEVER_EQUAL, else
+                             // the rank code itself) << BLU_LVL_NEVER_SHIFT: the integer level tests and the record read nothing else
     uint32_t cstride;        // words per shape row, multiple of 16
     // lcp8[i] = number of leading levels shared by sorted rows i and i+1.  In that order the levels shared by a
     // whole group of rows = min(lcp8[lo .. hi-1]) for the group's smallest/largest pos: a range-minimum query
@@ -57,6 +59,7 @@ struct TaxDev {
     uint32_t stride;         // words per lineage row, multiple of 32 (128 bytes)
     uint32_t node_base;      // word of the row where the node ids start (BLU_ROW_NODE_BASE)
     uint32_t max_depth;      // longest lineage: bounds the length bits of a (possibly corrupt) row id
+    uint32_t n_shapes;       // rows of codes / kthr (>= 1): bounds a (possibly corrupt) shape id
 };
 
 #define BLU_ROW_IV_LEVELS 20u    // levels whose neighbour run lengths sit in the row (words 1..10)
@@ -64,6 +67,9 @@ struct TaxDev {
 #define BLU_ROW_NODE_BASE 11u    // first node-id word of a row
 #define BLU_KTHR_BITS 17u
 #define BLU_KTHR_NEVER ((1u << BLU_KTHR_BITS) - 1u)
+#define BLU_LVL_RANK_SHIFT 18u
+#define BLU_LVL_NEVER_SHIFT 28u
+#define BLU_HINT_BITS 15u        // shape hint of a packed side record: word 1 = pident_milli | (shape id + 1) << BLU_KTHR_BITS, 0 = none
 #define BLU_PACK_CUT_BITS 12u
 #define BLU_PACK_CODE_BITS 10u
 #define BLU_PACK_CODE_MASK ((1u << BLU_PACK_CODE_BITS) - 1u)
@@ -74,12 +80,13 @@ struct HitsDev {
     const uint32_t* tax_row;
     const double* pident;          // f64 layout, or nullptr
     const uint32_t* pident_milli;  // milli-percent layout, or nullptr
-    const uint32_t* packed;        // packed layout: 4 words per hit {tax_row, pident_milli, align_len, acc_rank}, or nullptr
+    const uint32_t* packed;        // packed layout: 4 words per hit {tax_row, pident_milli | shape hint << 17, align_len, acc_rank}, or nullptr
     const int32_t* align_len;
     const uint32_t* acc_rank;
     const uint64_t* seg_off;
     uint64_t n_hits;
     uint64_t n_queries;
+    const uint32_t* packed64 = nullptr;   // 6 words per hit {tax_row, shape hint << 17, align_len, acc_rank, pident f64 lo, hi}, or nullptr
 };
 
 // launch wrapper implemented in consensus_kernel.hip
@@ -119,6 +126,8 @@ struct blu_taxonomy {
     uint8_t* d_rmq = nullptr;
     uint32_t rmq_nb = 0;
     std::vector<uint32_t> pos_of;            // caller's tax_row -> sorted position
+    std::vector<uint16_t> hint_of_pos;       // sorted position -> shape hint of the packed layout (shape id + 1, 0 = none)
+    uint16_t* d_hint_of_pos = nullptr;
     double* d_cutvals = nullptr;
     uint32_t* d_codes = nullptr;
     uint32_t* d_kthr = nullptr;

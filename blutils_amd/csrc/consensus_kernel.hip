@@ -75,9 +75,7 @@ namespace blu {
 #define BLU_X_SKIP_GATHER false
 #endif
 #endif
-#ifndef BLU_X_EARLY_CODES
-#define BLU_X_EARLY_CODES 0   // timing only: 1 = codes / kthr rows requested with the reference row, shape 0; 2 = a hashed shape
-#endif
+
 
 // In-kernel stamps (experiment builds only: -DBLU_EXPERIMENTS -DBLU_X_STAMPS): s_memtime at the phase boundaries of the
 // stream kernel, summed per wave and written over the first records of `out` when the wave is done (scripts/stamps.py).
@@ -289,6 +287,12 @@ __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
 #define META_SLOW 0x80000000u
 #define META_DENSE 0x40000000u   // the query was reduced by a dense step of phase 1: nothing of it in the list
 #define KEY_PID_BITS 17u         // milli-percent perc_identity below 2^17 packs with the lineage length into one sort word
+// Comparison-ready list entries (gather_list -> phase 2a): .x = sorted position | high 7 bits of the shape hint << 25,
+// .y = lineage length << 25 | milli-percent << 8 | low 8 bits of the shape hint (masked out of the compares),
+// .z = align_length biased to compare unsigned, .w = accession rank
+#define KEYED_LEN_SHIFT 25u
+#define KEYED_PID_SHIFT 8u
+#define PM_MASK ((1u << KEY_PID_BITS) - 1u)
 #ifndef SHORT_SEG
 #define SHORT_SEG 128u           // segments up to here are streamed (4 .. 32 lanes per query); longer ones take the sparse long pass
 #endif
@@ -404,18 +408,20 @@ static_assert(RING_CHUNKS <= 16, "wait_vmcnt covers 0..15 younger chunks");
 #define BLU_WAVES_PER_SIMD 3   // one 768-thread block per CU: 168 VGPRs
 #endif
 // LAYOUT: 0 = perc_identity f64 column, 1 = milli-percent u32 column, 2 = packed 16-byte side records
-// {tax_row, pident_milli, align_len, acc_rank} next to the bit-score column
+// {tax_row, pident_milli | shape hint << 17, align_len, acc_rank} next to the bit-score column, 3 = 24-byte side records
+// {tax_row, shape hint << 17, align_len, acc_rank, perc_identity f64}
 // RING = false: the same kernel without the bit-score ring — every task takes the direct-load phase 1 — at 128 VGPRs and
 // 16 waves per CU instead of 168 and 12.  A table whose tasks are mostly of mixed segment lengths (none of them could use
 // the ring) runs on that one: its phase 1 is bound by instruction issue, which a fourth wave per SIMD helps and the
 // ring's registers and LDS do not (C5: 0.626 -> 0.573 ms).  blu_classify_tasks decides per run (work_count[9]); the
 // kernel of the other kind returns at once.
 template <int STRAT, int LAYOUT, bool RING>
-__global__ __launch_bounds__((RING || LAYOUT == 0) ? BLOCK_A : BLOCK_N, (RING || LAYOUT == 0) ? BLU_WAVES_PER_SIMD : BLU_N_WAVES_PER_SIMD)
+__global__ __launch_bounds__((RING || LAYOUT == 0 || LAYOUT == 3) ? BLOCK_A : BLOCK_N, (RING || LAYOUT == 0 || LAYOUT == 3) ? BLU_WAVES_PER_SIMD : BLU_N_WAVES_PER_SIMD)
 void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out, uint32_t* __restrict__ worklist, uint32_t* __restrict__ work_count,
                                  uint32_t forced) {
-    constexpr bool PID32 = LAYOUT != 0, PACKED = LAYOUT == 2;
-    constexpr uint32_t BLOCK_T = (RING || LAYOUT == 0) ? BLOCK_A : BLOCK_N, WAVES_T = BLOCK_T / WAVE;   // (the f64 layout does not fit 128 VGPRs)
+    // PACKED: 16-byte side records (milli-percent), WIDE: 24-byte side records (f64 perc_identity in words 4, 5)
+    constexpr bool PID32 = LAYOUT == 1 || LAYOUT == 2, PACKED = LAYOUT == 2, WIDE = LAYOUT == 3;
+    constexpr uint32_t BLOCK_T = (RING || !PID32) ? BLOCK_A : BLOCK_N, WAVES_T = BLOCK_T / WAVE;   // (the f64 layouts do not fit 128 VGPRs)
     constexpr uint32_t CAP = WaveLds<!PID32, RING>::CAP;   // list entries per wave task
     // forced: the host launched this kind alone (it remembered the kind of the handle's last table); else both kinds are
     // in the stream and the one blu_classify_tasks did not pick returns
@@ -504,6 +510,8 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
         const uint64_t q = q0 + (uint32_t)lane;
         const uint32_t row0 = (uint32_t)my_off;
+        // (r_len: lineage length of the reference row in bits 0..7, the shape hint of its side record above — packed layout,
+        // 0 = none: the shape then comes from the row)
         uint32_t mode = 3, r_len = 0, r_row = 0, r_pos = 0, r_hdr = 0, minlen = 0, d = 0, rec_kind = 0, g_lo = 0, g_hi = 0;
         typedef typename PidKey<PID32>::type PK;
         PK r_pid = 0, max_pid = 0;   // fold(0.0, max): find_multi_taxa_consensus.rs:182-185
@@ -522,10 +530,11 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         const auto rs_bs = __builtin_amdgcn_make_buffer_rsrc((void*)(h.bitscore + task_start), 0, rem4, 0x00020000);
         // (packed layout: rs_tax is the descriptor of the 16-byte records; the other three column descriptors are unused)
         const auto rs_tax = PACKED ? __builtin_amdgcn_make_buffer_rsrc((void*)(h.packed + 4 * task_start), 0, (uint32_t)(rem * 16), 0x00020000)
+                            : WIDE ? __builtin_amdgcn_make_buffer_rsrc((void*)(h.packed64 + 6 * task_start), 0, (uint32_t)(rem * 24), 0x00020000)
                                    : __builtin_amdgcn_make_buffer_rsrc((void*)(h.tax_row + task_start), 0, rem4, 0x00020000);
         const auto rs_aln = __builtin_amdgcn_make_buffer_rsrc((void*)(h.align_len + task_start), 0, rem4, 0x00020000);
         const auto rs_acc = __builtin_amdgcn_make_buffer_rsrc((void*)(h.acc_rank + task_start), 0, rem4, 0x00020000);
-        const auto rs_pid = PACKED ? rs_tax : PID32 ? __builtin_amdgcn_make_buffer_rsrc((void*)(h.pident_milli + task_start), 0, rem4, 0x00020000)
+        const auto rs_pid = (PACKED || WIDE) ? rs_tax : PID32 ? __builtin_amdgcn_make_buffer_rsrc((void*)(h.pident_milli + task_start), 0, rem4, 0x00020000)
                                   : __builtin_amdgcn_make_buffer_rsrc((void*)(h.pident + task_start), 0, rem8, 0x00020000);
         // per-query {first row, row count} of the task, relative to task_start; count 0 also for segments > 64 rows
         // (those go to the worklist in phase 2a) so that phase 1 simply finds no top row in them
@@ -583,7 +592,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         // of 500 target sequences rarely leaves more than that after blutils' identity / coverage filters), so that
         // short segments do not leave most lanes without a row to load and long ones still share the lane-per-query
         // finalisation of phase 2.
-        struct StepRegs { u32x4 vbs, vtax, vp01, vp23, valn, vacc; int left; uint32_t qi; };
+        struct StepRegs { u32x4 vbs, vtax, vp01, vp23, valn, vacc, vq; int left; uint32_t qi; };   // (vq: wide records only)
         // The non-bit-score values of a lane's four rows.  Column layouts: one 16-byte load per column (vtax, vp01[/vp23],
         // valn, vacc = the column's four rows).  Packed layout: one 16-byte load per ROW (vtax, vp01, valn, vacc = rows
         // 0..3, each {tax_row, pident_milli, align_len, acc_rank}), and only the rows in `rows` are requested.
@@ -597,6 +606,20 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 R.valn = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, (any && (rows & 4u)) ? base + 32u : 0xFFFFFFC0u, 0, STREAM_AUX);
                 R.vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, (any && (rows & 8u)) ? base + 48u : 0xFFFFFFC0u, 0, STREAM_AUX);
                 R.vp23 = R.vp01;
+                return;
+            }
+            if (WIDE) {   // 24-byte records: the first 16 bytes of row r in vtax / vp01 / valn / vacc, its f64 in (vp23, vq)[r]
+                const uint32_t base = voff * 6u;
+                R.vtax = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, (any && (rows & 1u)) ? base : 0xFFFFFFC0u, 0, STREAM_AUX);
+                R.vp01 = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, (any && (rows & 2u)) ? base + 24u : 0xFFFFFFC0u, 0, STREAM_AUX);
+                R.valn = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, (any && (rows & 4u)) ? base + 48u : 0xFFFFFFC0u, 0, STREAM_AUX);
+                R.vacc = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, (any && (rows & 8u)) ? base + 72u : 0xFFFFFFC0u, 0, STREAM_AUX);
+                const u32x2 p0 = __builtin_amdgcn_raw_buffer_load_b64(rs_tax, (any && (rows & 1u)) ? base + 16u : 0xFFFFFFE0u, 0, STREAM_AUX);
+                const u32x2 p1 = __builtin_amdgcn_raw_buffer_load_b64(rs_tax, (any && (rows & 2u)) ? base + 40u : 0xFFFFFFE0u, 0, STREAM_AUX);
+                const u32x2 p2 = __builtin_amdgcn_raw_buffer_load_b64(rs_tax, (any && (rows & 4u)) ? base + 64u : 0xFFFFFFE0u, 0, STREAM_AUX);
+                const u32x2 p3 = __builtin_amdgcn_raw_buffer_load_b64(rs_tax, (any && (rows & 8u)) ? base + 88u : 0xFFFFFFE0u, 0, STREAM_AUX);
+                R.vp23 = u32x4{p0.x, p0.y, p1.x, p1.y};
+                R.vq = u32x4{p2.x, p2.y, p3.x, p3.y};
                 return;
             }
             const uint32_t vo = any ? voff : 0xFFFFFFF0u;
@@ -618,6 +641,14 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             if (PACKED) {   // the loaded record goes to the list as one 16-byte write
                 const u32x4 rec = r == 0 ? R.vtax : (r == 1 ? R.vp01 : (r == 2 ? R.valn : R.vacc));
                 L.rec[idx] = make_uint4(rec.x, rec.y, rec.z, rec.w);
+                return;
+            }
+            if (WIDE) {     // {tax_row, pident low word, align_len, acc_rank} + the high word: the list entry of the f64 layout
+                const u32x4 rec = r == 0 ? R.vtax : (r == 1 ? R.vp01 : (r == 2 ? R.valn : R.vacc));
+                const uint32_t plo = r == 0 ? R.vp23.x : (r == 1 ? R.vp23.z : (r == 2 ? R.vq.x : R.vq.z));
+                const uint32_t phi = r == 0 ? R.vp23.y : (r == 1 ? R.vp23.w : (r == 2 ? R.vq.y : R.vq.w));
+                L.rec[idx] = make_uint4(rec.x, plo, rec.z, rec.w);
+                L.p1[idx] = phi;
                 return;
             }
             const uint32_t xt[4] = {R.vtax.x, R.vtax.y, R.vtax.z, R.vtax.w}, xa[4] = {R.valn.x, R.valn.y, R.valn.z, R.valn.w};
@@ -734,7 +765,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 }
 #pragma unroll
                 for (int u = 0; u < BLU_STEP_SETS; ++u) {
-                    asm volatile("" ::"v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc));
+                    asm volatile("" ::"v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc)); if (WIDE) asm volatile("" ::"v"(R[u].vq));
                     emit(R[u], T[u]);
                 }
                 if (!all_fit) { stop_q = qb + QPS * BLU_STEP_SETS; break; }   // the list is full: the rest of the task in the next round
@@ -754,14 +785,14 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 for (int u = 0; u < BLU_STEP_SETS; ++u) { asm volatile("" ::"v"(R[u].vbs)); tops(R[u], T[u]); all_fit &= T[u].fits; }
 #pragma unroll
                 for (int u = 0; u < BLU_STEP_SETS; ++u) {
-                    asm volatile("" ::"v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc));
+                    asm volatile("" ::"v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc)); if (WIDE) asm volatile("" ::"v"(R[u].vq));
                     emit(R[u], T[u]);
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < BLU_STEP_SETS; ++u) {
                     // every loaded register is read here on every path (otherwise hipcc parks a vmcnt(0) at the loop head)
-                    asm volatile("" ::"v"(R[u].vbs), "v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc));
+                    asm volatile("" ::"v"(R[u].vbs), "v"(R[u].vtax), "v"(R[u].vp01), "v"(R[u].vp23), "v"(R[u].valn), "v"(R[u].vacc)); if (WIDE) asm volatile("" ::"v"(R[u].vq));
                     tops(R[u], T[u]);
                     all_fit &= T[u].fits;
                     emit(R[u], T[u]);
@@ -974,7 +1005,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                         const bool take = on & ((kmin == 0xFFFFFFFFu) | better(K, rec.w, gp, BK, bacc, bpos));
                         BK = take ? K : BK; bacc = take ? rec.w : bacc; bpos = take ? gp : bpos; brow = take ? pos : brow;
                         kmin = on ? umin(kmin, k1) : kmin;
-                        const uint32_t pmo = pm | (rec.y >= (1u << KEY_PID_BITS) ? 0x80000000u : 0u);
+                        const uint32_t pmo = pm | ((!PACKED && rec.y >= (1u << KEY_PID_BITS)) ? 0x80000000u : 0u);   // (packed: bits 17.. are the shape hint)
                         pmax = (on && pmo > pmax) ? pmo : pmax;
                         dlo = on ? umin(dlo, pos) : dlo;
                         dhi = (on && pos > dhi) ? pos : dhi;
@@ -1174,7 +1205,11 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 const uint32_t row = (d >> DESC_SUB_BITS) + i;
                 gpos[u] = (d & ((1u << DESC_SUB_BITS) - 1u)) * scan_rpl + i;
                 if (PACKED) g[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, valid ? row * 16u : 0xFFFFFFC0u, 0, GATHER_AUX);
-                else {
+                else if (WIDE) {
+                    g[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, valid ? row * 24u : 0xFFFFFFC0u, 0, GATHER_AUX);
+                    const u32x2 p = __builtin_amdgcn_raw_buffer_load_b64(rs_tax, valid ? row * 24u + 16u : 0xFFFFFFE0u, 0, GATHER_AUX);
+                    g[u].y = p.x; ghi[u] = p.y;   // (the shape hint in word 1 is not carried through the list of this layout)
+                } else {
                     const uint32_t o4 = valid ? row * 4u : 0xFFFFFFF0u;
                     g[u].x = __builtin_amdgcn_raw_buffer_load_b32(rs_tax, o4, 0, GATHER_AUX);
                     if (PID32) g[u].y = __builtin_amdgcn_raw_buffer_load_b32(rs_pid, o4, 0, GATHER_AUX);
@@ -1194,7 +1229,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             bool ovf = false;
             if (PID32) {
 #pragma unroll
-                for (int u = 0; u < NG; ++u) ovf |= ((uint32_t)u * WAVE + (uint32_t)lane < fill_ring) && g[u].y >= (1u << KEY_PID_BITS);
+                for (int u = 0; u < NG; ++u) ovf |= !PACKED && ((uint32_t)u * WAVE + (uint32_t)lane < fill_ring) && g[u].y >= (1u << KEY_PID_BITS);
             }
             keyed = PID32 && __ballot(ovf) == 0ull && fill == fill_ring;   // (entries appended by the long pass are plain records)
 #pragma unroll
@@ -1202,8 +1237,9 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 const uint32_t idx = (uint32_t)u * WAVE + (uint32_t)lane;
                 if (idx < fill_ring) {
                     if (keyed) {
-                        const uint32_t len = umin(g[u].x >> BLU_ROW_BITS, t.max_depth);
-                        L.rec[idx] = make_uint4((g[u].x & ROW_MASK) | (len << BLU_ROW_BITS), (len << KEY_PID_BITS) | g[u].y, g[u].z ^ 0x80000000u, g[u].w);
+                        const uint32_t len = umin(g[u].x >> BLU_ROW_BITS, t.max_depth), hint = g[u].y >> KEY_PID_BITS;   // (hint: packed layout only, else 0)
+                        L.rec[idx] = make_uint4((g[u].x & ROW_MASK) | ((hint >> 8) << BLU_ROW_BITS),
+                                                (len << KEYED_LEN_SHIFT) | ((g[u].y & PM_MASK) << KEYED_PID_SHIFT) | (hint & 0xFFu), g[u].z ^ 0x80000000u, g[u].w);
                     } else L.rec[idx] = make_uint4(g[u].x, g[u].y, g[u].z, g[u].w);
                     L.pq[idx] = (uint16_t)gpos[u];
                     if (!PID32) L.p1[idx] = ghi[u];
@@ -1351,7 +1387,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             // shortest lineage, group-max pident (find_multi_taxa_consensus.rs:39-68,142-145,182-185) and the span
             // [lo, hi] of the group in the sorted lineage order
             uint32_t err = 0, err_pos = 0, nan_pos = 0xFFFFFFFFu;
-            uint32_t b_len = 0, b_acc = 0, lo = 0xFFFFFFFFu, hi = 0, l_minlen = 0xFFFFFFFFu, l_row = 0, l_pos = 0;
+            uint32_t b_len = 0, b_acc = 0, lo = 0xFFFFFFFFu, hi = 0, l_minlen = 0xFFFFFFFFu, l_row = 0, l_pos = 0, l_hint = 0;
             int b_aln = 0;
             PK b_pid = 0, l_maxpid = 0;   // fold(0.0, max): find_multi_taxa_consensus.rs:182-185
             const uint32_t last_e = k ? k - 1u : 0u;
@@ -1361,23 +1397,26 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             if (PID32 && keyed) {
                 uint64_t BK = 0;                         // best (length, perc_identity, align_length) so far
                 uint32_t kmin = 0xFFFFFFFFu, pmax = 0;
+                uint32_t l_x = 0, l_y = 0;               // .x / .y of the entry taken last: its position and shape hint come out after the loop
                 auto step = [&](const uint4 x, const uint32_t xpos, const bool is_first) {
                     const uint32_t pos = x.x & ROW_MASK;
-                    const bool unmatched = pos >= t.n_tax, bad = x.x < (1u << BLU_ROW_BITS);
+                    const bool unmatched = pos >= t.n_tax, bad = x.y < (1u << KEYED_LEN_SHIFT);   // (lineage length 0)
                     const bool first_err = (err == 0) & (unmatched | bad);
                     err = first_err ? (unmatched ? (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID : (uint32_t)BLU_ST_ERR_BAD_LINEAGE) : err;
                     err_pos = first_err ? xpos : err_pos;
                     kmin = umin(kmin, x.y);
                     lo = umin(lo, pos);
                     hi = pos > hi ? pos : hi;
-                    const uint32_t pm = x.y & ((1u << KEY_PID_BITS) - 1u);
+                    const uint32_t ky = x.y & ~0xFFu;      // (length, perc_identity): the hint bits do not order anything
+                    const uint32_t pm = (x.y >> KEYED_PID_SHIFT) & PM_MASK;
                     pmax = pm > pmax ? pm : pmax;
-                    const uint64_t K = ((uint64_t)x.y << 32) | x.z;
+                    const uint64_t K = ((uint64_t)ky << 32) | x.z;
                     const bool gt = (K > BK) | ((K == BK) & (x.w > b_acc)), eq = (K == BK) & (x.w == b_acc);
                     const bool take = is_first | (STRAT == BLU_RELAXED ? (gt | eq) : !(gt | eq));
                     BK = take ? K : BK;
                     b_acc = take ? x.w : b_acc;
-                    l_row = take ? pos : l_row;
+                    l_x = take ? x.x : l_x;
+                    l_y = take ? x.y : l_y;
                     l_pos = take ? xpos : l_pos;
                 };
                 // four entries per trip, their LDS reads issued together: one read latency per four entries
@@ -1394,9 +1433,11 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     for (uint32_t j = 0; j < 4; ++j) step(x[j], xp[j], e == 0 && j == 0);
                 }
                 const uint32_t k1 = (uint32_t)(BK >> 32);
-                b_len = k1 >> KEY_PID_BITS;
-                l_minlen = kmin >> KEY_PID_BITS;
-                if constexpr (PID32) { b_pid = k1 & ((1u << KEY_PID_BITS) - 1u); l_maxpid = pmax; }
+                b_len = k1 >> KEYED_LEN_SHIFT;
+                l_minlen = kmin >> KEYED_LEN_SHIFT;
+                l_row = l_x & ROW_MASK;
+                l_hint = ((l_x >> BLU_ROW_BITS) << 8) | (l_y & 0xFFu);
+                if constexpr (PID32) { b_pid = (k1 >> KEYED_PID_SHIFT) & PM_MASK; l_maxpid = pmax; }
             } else {
                 for (uint32_t e = 0; e < kmax; ++e) {
                     const uint4 x = nx_rec;              // {row id, pident, align_len, accession rank}
@@ -1410,7 +1451,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     err = first_err ? (unmatched ? (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID : (uint32_t)BLU_ST_ERR_BAD_LINEAGE) : err;
                     err_pos = first_err ? xpos : err_pos;
                     PK xpid;
-                    if constexpr (PID32) xpid = x.y;
+                    if constexpr (PID32) xpid = PACKED ? (x.y & PM_MASK) : x.y;   // (packed: the bits above are the shape hint)
                     else {
                         xpid = __hiloint2double((int)L.p1[idx], (int)x.y);
                         nan_pos = (nan_pos == 0xFFFFFFFFu && xpid != xpid) ? xpos : nan_pos;
@@ -1426,6 +1467,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     b_acc = take ? x.w : b_acc;
                     l_row = take ? pos : l_row;
                     l_pos = take ? xpos : l_pos;
+                    if (PACKED) l_hint = take ? (x.y >> KEY_PID_BITS) : l_hint;
                 }
             }
             if (pend) {
@@ -1440,7 +1482,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 else if (err) { pack_status(ra, rb, err, row0 + err_pos); rec_kind = 1; }
                 else if (!PID32 && nan_pos != 0xFFFFFFFFu) { pack_status(ra, rb, BLU_ST_ERR_BAD_PIDENT, row0 + nan_pos); rec_kind = 1; }
                 else {
-                    r_len = b_len; r_pid = b_pid; r_row = l_row; r_pos = l_pos; minlen = l_minlen; max_pid = l_maxpid;
+                    r_len = b_len | (l_hint << 8); r_pid = b_pid; r_row = l_row; r_pos = l_pos; minlen = l_minlen; max_pid = l_maxpid;
                     mode = k == 1 ? 2u : 0u;
                     g_lo = lo; g_hi = hi;    // span of the group in sorted order: phase 2c turns it into the shared levels
                 }
@@ -1462,11 +1504,12 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         else if (mode != 3) {
             const bool single = mode == 2;
             rec_kind = 1;
+            const uint32_t r_hint = r_len >> 8;
+            r_len &= 0xFFu;
             // The reference row: header, neighbour run lengths of 20 levels and the node ids in one 128-byte line (up to 20
             // levels), read with eight 16-byte loads issued back to back: one memory request.  (Reading the node id
             // later, after the codes lookup, fetched the line a second time for half of the queries: the stream had
-            // pushed it out of L2 in between.)  Per-level cutoff ids and rank codes come from the row of the shape in
-            // the codes table (L2-resident).
+            // pushed it out of L2 in between.)
             const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
             const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
             uint4 w[8];
@@ -1476,10 +1519,30 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const u32x4 x = __builtin_nontemporal_load(refv + k); w[k] = make_uint4(x.x, x.y, x.z, x.w); }
             }
+#elif defined(BLU_REF_AUX)
+            {   // (experiment: cache-policy bits on the reference-row loads; tables under 4 GB only)
+                const auto rs_lin = __builtin_amdgcn_make_buffer_rsrc((void*)t.lin, 0, (uint32_t)(t.n_tax * t.stride * 4u), 0x00020000);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs_lin, r_row * (t.stride * 4u) + 16u * k, 0, BLU_REF_AUX); w[k] = make_uint4(x.x, x.y, x.z, x.w); }
+            }
 #else
 #pragma unroll
             for (int k = 0; k < 8; ++k) w[k] = ref4[k];
 #endif
+            // What the finalisation needs per LEVEL depends on the row's shape only (TaxDev::kthr: threshold, rank code and
+            // max-allowed-rank bit in one word per level).  In the packed layout the side record of the reference hit carries
+            // the shape as a hint, so those words are requested NOW, together with the row, instead of after it: one memory
+            // round trip on the task's critical path instead of two.  The hint is checked against the row's header below; a
+            // lane whose hint is missing or wrong asks again with the shape the row gives.
+            uint4 ck[4] = {};
+            uint32_t shape_req = 0xFFFFFFFFu;
+            if constexpr (PACKED) {
+                const uint32_t guess = r_hint ? umin(r_hint - 1u, t.n_shapes - 1u) : 0u;
+                const uint4* kg = reinterpret_cast<const uint4*>(t.kthr + (uint64_t)guess * t.cstride);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ck[k] = kg[k];
+                shape_req = r_hint ? guess : 0xFFFFFFFFu;
+            }
             // Levels shared by the whole group (find_multi_taxa_consensus.rs:137-180): every row agrees with the reference row on
             // exactly the levels all rows of the span [lo, hi] share, and the scan never looks past the shortest lineage.
             // Seen from the reference row r that is the number of levels whose run reaches dl = r - lo rows to the left and
@@ -1515,93 +1578,67 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             const bool agree = single | (d >= minlen);
             if (!agree && d == 0) pack_status(ra, rb, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
             else {
-#if BLU_X_EARLY_CODES
-                const uint32_t x_shape = BLU_X_EARLY_CODES == 1 ? (r_row & 63u) : (r_row * 2654435761u) % 6000u;
-                const uint32_t* codes = t.codes + (uint64_t)x_shape * t.cstride;
-#else
-                const uint32_t* codes = t.codes + (uint64_t)(r_hdr >> 8) * t.cstride;
-#endif
+                const uint32_t shape = umin(r_hdr >> 8, t.n_shapes - 1u);
+                const uint32_t* codes = t.codes + (uint64_t)shape * t.cstride;
                 const uint4* codes4 = reinterpret_cast<const uint4*>(codes);
+                const uint32_t* lvl = t.kthr + (uint64_t)shape * t.cstride;
+                const uint4* lvl4 = reinterpret_cast<const uint4*>(lvl);
                 const uint32_t b = single ? len_ref : (agree ? minlen - 1 : d - 1);
                 const double ident = pid_f64<PID32>((single | agree) ? r_pid : max_pid);   // the one f64 the cutoff tests need
                 // Milli-percent layouts: `fl(k / 1000) >= c` is monotone in k, so every cutoff c has a smallest k that passes
                 // it (taxonomy.cpp: kthr, 17 bits, + 1 bit "fl(k / 1000) == c", i.e. `>` needs one more) and the level tests
                 // are integer compares of the query's milli-percent identity — no cutoff value is read.  Identities of
-                // 131.071 % and more (not BLAST output) take the f64 tests.
+                // 131.071 % and more (not BLAST output; the packed layout cannot hold them) take the f64 tests.
                 uint32_t ident_k = 0;
                 if constexpr (PID32) ident_k = (single | agree) ? r_pid : max_pid;
-                const bool by_k = PID32 && __ballot(ident_k >= BLU_KTHR_NEVER) == 0ull;
-#if BLU_X_EARLY_CODES
-                const uint4* kthr4 = reinterpret_cast<const uint4*>(t.kthr + (uint64_t)x_shape * t.cstride);
-#else
-                const uint4* kthr4 = reinterpret_cast<const uint4*>(t.kthr + (uint64_t)(r_hdr >> 8) * t.cstride);
-#endif
+                if constexpr (PACKED) ident_k = umin(ident_k, BLU_KTHR_NEVER - 1u);   // (records put together by hand with the one value blu_hits_pack refuses)
+                const bool by_k = PACKED || (PID32 && __ballot(ident_k >= BLU_KTHR_NEVER) == 0ull);
                 // linnaean_ranks.rs:174-212 + build_blast_consensus_identity.rs:67-82
                 uint64_t F = 0, A = 0;
                 uint32_t mar_level = BLU_NONE_U8, nF = 0;
-                uint64_t GE = 0, GT = 0;            // bit j: identity >= / > the cutoff of level j (no dependence between levels)
-                auto level_k = [&](uint32_t j, uint32_t wk) {
-                    const uint32_t kge = wk & BLU_KTHR_NEVER;
-                    GE |= (uint64_t)(ident_k >= kge) << j;
-                    GT |= (uint64_t)(ident_k >= kge + (wk >> BLU_KTHR_BITS)) << j;
-                };
-                auto level = [&](uint32_t j, uint32_t packed) {
-                    if (j < len_ref) {
-                        const uint32_t cid = packed & ((1u << BLU_PACK_CUT_BITS) - 1u);
-                        const double cj = cut_in_lds ? s_cut[cid] : t.cutvals[cid];
-                        if (mar_level == BLU_NONE_U8 && !(ident > cj)) mar_level = j;   // skip_while(identity > cutoff)
-                        if (ident >= cj) {                                             // filter(identity >= cutoff)
-                            F |= 1ull << j;
-                            if (nF <= b) A |= 1ull << j;                               // first (b + 1) elements of the filtered list
-                            ++nF;
-                        }
+                uint4 c[4] = {};
+                // the per-lane table of the level words / codes words of the first 16 levels: the list area of the wave (dead
+                // since phase 2a; the records are staged there afterwards), 16 words per lane, so that "the word of level j"
+                // with j different in every lane is one LDS read instead of a 16-way select chain over the registers
+                uint32_t* const stage = reinterpret_cast<uint32_t*>(&L.rec[0]) + (uint32_t)lane * 16u;
+                if constexpr (PID32) {
+                  if (by_k) {
+                    if (!PACKED || shape != shape_req) {       // no hint, or not the row's shape: the words of the shape the row gives
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) ck[k] = lvl4[k];
                     }
-                };
-                uint4 c[4], ck[4];
+                    STAMP_DRAIN
+                    STAMP(6)   // (5: run lengths / RMQ) level words arrive
+                    // bit j of NGE / NGT: identity < / <= the cutoff of level j.  ident_k - threshold is negative exactly then, and
+                    // v_alignbit shifts that sign bit into the mask: two instructions per test, levels taken from the deepest down
+                    // so that level 0 ends in bit 0.  No dependence between levels.
+                    uint64_t NGE = 0, NGT = 0;
+                    auto test4 = [&](const uint4 x, uint32_t& nge, uint32_t& ngt) {
+                        const uint32_t xs[4] = {x.w, x.z, x.y, x.x};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) c[k] = codes4[k];
-                if (by_k) {
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t dge = ident_k - (xs[i] & BLU_KTHR_NEVER);
+                            nge = __builtin_amdgcn_alignbit(nge, dge, 31);
+                            ngt = __builtin_amdgcn_alignbit(ngt, dge - ((xs[i] >> BLU_KTHR_BITS) & 1u), 31);
+                        }
+                    };
+                    {
+                        uint32_t nge = 0, ngt = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) ck[k] = kthr4[k];
-                }
-                STAMP_DRAIN
-                STAMP(6)   // (5: run lengths / RMQ) codes arrive
-                if (by_k) {
+                        for (int k = (BLU_X_SKIP_LEVELS ? -1 : 3); k >= 0; --k) test4(ck[k], nge, ngt);
+                        NGE = nge & 0xFFFFu; NGT = ngt & 0xFFFFu;
+                    }
+                    for (uint32_t k = 4; 4 * k < len_ref; ++k) {   // lineages deeper than 16 levels
+                        uint32_t nge = 0, ngt = 0;
+                        test4(lvl4[k], nge, ngt);
+                        NGE |= (uint64_t)(nge & 0xFu) << (4 * k); NGT |= (uint64_t)(ngt & 0xFu) << (4 * k);
+                    }
+                    uint4* const st4 = reinterpret_cast<uint4*>(stage);
 #pragma unroll
-                    for (int k = 0; k < (BLU_X_SKIP_LEVELS ? 0 : 4); ++k) { level_k(4 * k, ck[k].x); level_k(4 * k + 1, ck[k].y); level_k(4 * k + 2, ck[k].z); level_k(4 * k + 3, ck[k].w); }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < (BLU_X_SKIP_LEVELS ? 0 : 4); ++k) { level(4 * k, c[k].x); level(4 * k + 1, c[k].y); level(4 * k + 2, c[k].z); level(4 * k + 3, c[k].w); }
-                }
-                // codes word of level j again (rank codes of the reached / allowed levels): from the registers for the first
-                // 16 levels — going back to memory for them put a third dependent lookup on the task's critical path
-                const uint32_t cw[16] = {c[0].x, c[0].y, c[0].z, c[0].w, c[1].x, c[1].y, c[1].z, c[1].w,
-                                         c[2].x, c[2].y, c[2].z, c[2].w, c[3].x, c[3].y, c[3].z, c[3].w};
-                auto code_of = [&](uint32_t j) {
-                    uint32_t v = 0;
-                    if (j >= 16) v = codes[j];
-#pragma unroll
-                    for (uint32_t i = 0; i < 16; ++i) v = (j == i) ? cw[i] : v;
-                    return v;
-                };
-                for (uint32_t k = 4; 4 * k < len_ref; ++k) {   // lineages deeper than 16 levels
-                    if (by_k) { const uint4 x = kthr4[k]; level_k(4 * k, x.x); level_k(4 * k + 1, x.y); level_k(4 * k + 2, x.z); level_k(4 * k + 3, x.w); }
-                    else { const uint4 x = codes4[k]; level(4 * k, x.x); level(4 * k + 1, x.y); level(4 * k + 2, x.z); level(4 * k + 3, x.w); }
-                }
-                // node id of level j: words 11..30 of the line are in registers, deeper levels are read from the row
-                const uint32_t nid[20] = {w[2].w, w[3].x, w[3].y, w[3].z, w[3].w, w[4].x, w[4].y, w[4].z, w[4].w, w[5].x,
-                                          w[5].y, w[5].z, w[5].w, w[6].x, w[6].y, w[6].z, w[6].w, w[7].x, w[7].y, w[7].z};
-                auto node_of = [&](uint32_t j) {
-                    uint32_t v = 0;
-                    if (j >= 20) v = ref[BLU_ROW_NODE_BASE + j];
-#pragma unroll
-                    for (uint32_t i = 0; i < 20; ++i) v = (j == i) ? nid[i] : v;
-                    return v;
-                };
-                if (by_k) {
+                    for (int k = 0; k < 4; ++k) st4[k] = ck[k];
                     const uint64_t lenmask = len_ref >= 64u ? ~0ull : ((1ull << len_ref) - 1ull);
-                    F = GE & lenmask;                                                // filter(identity >= cutoff)
-                    const uint64_t NG = ~GT & lenmask;                               // skip_while(identity > cutoff): first level that stops it
+                    F = ~NGE & lenmask;                                              // filter(identity >= cutoff)
+                    const uint64_t NG = NGT & lenmask;                               // skip_while(identity > cutoff): first level that stops it
                     mar_level = NG ? (uint32_t)__builtin_ctzll(NG) : (uint32_t)BLU_NONE_U8;
                     // the first (b + 1) elements of the filtered list: everything up to the set bit of rank b, if F has that many
                     A = F;
@@ -1615,23 +1652,72 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                         pos += (r >= (x & 1u)) ? 1u : 0u;
                         A = F & ((2ull << pos) - 1ull);
                     }
+                  }
                 }
+                if (!by_k) {
+                    auto level = [&](uint32_t j, uint32_t packed) {
+                        if (j < len_ref) {
+                            const uint32_t cid = packed & ((1u << BLU_PACK_CUT_BITS) - 1u);
+                            const double cj = cut_in_lds ? s_cut[cid] : t.cutvals[cid];
+                            if (mar_level == BLU_NONE_U8 && !(ident > cj)) mar_level = j;   // skip_while(identity > cutoff)
+                            if (ident >= cj) {                                             // filter(identity >= cutoff)
+                                F |= 1ull << j;
+                                if (nF <= b) A |= 1ull << j;                               // first (b + 1) elements of the filtered list
+                                ++nF;
+                            }
+                        }
+                    };
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) c[k] = codes4[k];
+                    STAMP_DRAIN
+                    STAMP(6)   // (5: run lengths / RMQ) codes arrive
+#pragma unroll
+                    for (int k = 0; k < (BLU_X_SKIP_LEVELS ? 0 : 4); ++k) { level(4 * k, c[k].x); level(4 * k + 1, c[k].y); level(4 * k + 2, c[k].z); level(4 * k + 3, c[k].w); }
+                    for (uint32_t k = 4; 4 * k < len_ref; ++k) {   // lineages deeper than 16 levels
+                        const uint4 x = codes4[k]; level(4 * k, x.x); level(4 * k + 1, x.y); level(4 * k + 2, x.z); level(4 * k + 3, x.w);
+                    }
+                    uint4* const st4 = reinterpret_cast<uint4*>(stage);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) st4[k] = c[k];
+                }
+                // {canonical rank code, max-allowed-rank code} of level j (the lane's own words: written and read by the same lane)
+                auto ranks_of = [&](const uint32_t j, uint32_t& rank, uint32_t& mar) {
+                    const uint32_t v = j < 16u ? stage[j] : (by_k ? lvl[j] : codes[j]);
+                    if (by_k) { rank = (v >> BLU_LVL_RANK_SHIFT) & BLU_PACK_CODE_MASK; mar = ((v >> BLU_LVL_NEVER_SHIFT) & 1u) ? (uint32_t)BLU_MAR_NEVER_EQUAL : rank; }
+                    else { rank = packed_rank(v); mar = packed_mar(v); }
+                };
+                // node id of level j: words 11..30 of the line are in registers, deeper levels are read from the row
+                const uint32_t nid[20] = {w[2].w, w[3].x, w[3].y, w[3].z, w[3].w, w[4].x, w[4].y, w[4].z, w[4].w, w[5].x,
+                                          w[5].y, w[5].z, w[5].w, w[6].x, w[6].y, w[6].z, w[6].w, w[7].x, w[7].y, w[7].z};
+                auto node_of = [&](uint32_t j) {
+                    uint32_t v = 0;
+                    if (j >= 20) v = ref[BLU_ROW_NODE_BASE + j];
+#pragma unroll
+                    for (uint32_t i = 0; i < 20; ++i) v = (j == i) ? nid[i] : v;
+                    return v;
+                };
                 if (agree) A = F;                                                  // single hit / single-flag branch (:74-75)
                 if (single) {
                     if (!A) pack_status(ra, rb, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, row0 + r_pos);   // find_single_query_consensus.rs:113-119
                     else {
                         const uint32_t last = (uint32_t)last_lane(A);
-                        pack_result(ra, rb, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, packed_rank(code_of(last)), BLU_NONE_U16,
+                        uint32_t rank_last, mar_unused;
+                        ranks_of(last, rank_last, mar_unused);
+                        pack_result(ra, rb, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, rank_last, BLU_NONE_U16,
                                      node_of(last), row0 + r_pos, A, ident);
                     }
                 } else {
                     const uint32_t last = A ? (uint32_t)last_lane(A) : b;          // .last().unwrap_or(taxonomy[bean_index])
                     uint32_t flags = agree ? BLU_FLAG_AGREE : 0u, mar_code = BLU_NONE_U16;
+                    uint32_t rank_last, rank_b, mar_unused;
+                    ranks_of(last, rank_last, mar_unused);
                     if (mar_level != BLU_NONE_U8) {
-                        mar_code = packed_mar(code_of(mar_level));
-                        if (mar_code != packed_rank(code_of(b))) flags |= BLU_FLAG_MUTATED;   // bean.reached_rank != allowed_rank (:35-37)
+                        uint32_t rank_unused;
+                        ranks_of(mar_level, rank_unused, mar_code);
+                        ranks_of(b, rank_b, mar_unused);
+                        if (mar_code != rank_b) flags |= BLU_FLAG_MUTATED;         // bean.reached_rank != allowed_rank (:35-37)
                     }
-                    pack_result(ra, rb, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, packed_rank(code_of(last)), mar_code,
+                    pack_result(ra, rb, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, rank_last, mar_code,
                                  node_of(last), row0 + r_pos, A, ident);
                 }
             }
@@ -1730,7 +1816,7 @@ template <int STRAT, int LAYOUT>
 __global__ __launch_bounds__(BLOCK_B, BLU_B_WAVES_PER_SIMD) void blu_consensus_long_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                  const uint32_t* __restrict__ worklist,
                                                                  const uint32_t* __restrict__ work_count) {
-    constexpr bool PID32 = LAYOUT != 0, PACKED = LAYOUT == 2;
+    constexpr bool PID32 = LAYOUT == 1 || LAYOUT == 2, PACKED = LAYOUT == 2, WIDE = LAYOUT == 3;
     __shared__ uint32_t s_slot[BLOCK_B / WAVE][SLOT_CAP];   // rows of the top group found so far (segments kept in registers)
     const int lane = lane_id();
     uint32_t* const slot = s_slot[__builtin_amdgcn_readfirstlane(threadIdx.x / WAVE)];
@@ -1745,12 +1831,13 @@ __global__ __launch_bounds__(BLOCK_B, BLU_B_WAVES_PER_SIMD) void blu_consensus_l
         start = uniform64(start);
         const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)(end - start));   // n_hits < 2^32
         const int32_t* c_bs = h.bitscore + start;
-        const uint32_t* c_tax = PACKED ? nullptr : h.tax_row + start;
-        const double* c_pid = PID32 ? nullptr : h.pident + start;
+        const uint32_t* c_tax = (PACKED || WIDE) ? nullptr : h.tax_row + start;
+        const double* c_pid = (PID32 || WIDE) ? nullptr : h.pident + start;
         const uint32_t* c_pm = (PID32 && !PACKED) ? h.pident_milli + start : nullptr;
-        const int32_t* c_aln = PACKED ? nullptr : h.align_len + start;
-        const uint32_t* c_acc = PACKED ? nullptr : h.acc_rank + start;
+        const int32_t* c_aln = (PACKED || WIDE) ? nullptr : h.align_len + start;
+        const uint32_t* c_acc = (PACKED || WIDE) ? nullptr : h.acc_rank + start;
         const u32x4* c_pk = PACKED ? reinterpret_cast<const u32x4*>(h.packed) + start : nullptr;   // 16-byte records
+        const u32x2* c_pw = WIDE ? reinterpret_cast<const u32x2*>(h.packed64) + 3 * start : nullptr;   // 24-byte records
         // group size, errors in file order, lane-local best key / shortest lineage / max pident (filled by either path below)
         uint32_t k = 0, err_status = 0, err_row = 0;
         uint32_t have = 0, b_len = 0, b_acc = 0, b_pos = 0, b_row = 0, l_minlen = 0xFFFFFFFFu;
@@ -1774,7 +1861,11 @@ __global__ __launch_bounds__(BLOCK_B, BLU_B_WAVES_PER_SIMD) void blu_consensus_l
                 uint32_t tax, acc;
                 int aln;
                 double pid;
-                if (PACKED) { const u32x4 rec = c_pk[i]; tax = rec.x; pid = milli_to_f64(rec.y); aln = (int)rec.z; acc = rec.w; }
+                if (PACKED) { const u32x4 rec = c_pk[i]; tax = rec.x; pid = milli_to_f64(rec.y & PM_MASK); aln = (int)rec.z; acc = rec.w; }   // (bits 17.. of word 1: the shape hint)
+                else if (WIDE) {
+                    const u32x2 a = c_pw[3ull * i], b = c_pw[3ull * i + 1], c = c_pw[3ull * i + 2];
+                    tax = a.x; aln = (int)b.x; acc = b.y; pid = __hiloint2double((int)c.y, (int)c.x);
+                }
                 else { tax = c_tax[i]; pid = PID32 ? milli_to_f64(c_pm[i]) : c_pid[i]; aln = c_aln[i]; acc = c_acc[i]; }
                 const uint32_t pos = tax & ROW_MASK;
                 const bool unmatched = top && pos >= t.n_tax;
@@ -2058,7 +2149,7 @@ static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hip
         hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT, true>), dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count, forced);
     }
     if (known_kind != 1u) {
-        constexpr uint32_t block_n = LAYOUT == 0 ? BLOCK_A : BLOCK_N;
+        constexpr uint32_t block_n = (LAYOUT == 0 || LAYOUT == 3) ? BLOCK_A : BLOCK_N;
         const uint64_t want = (n_tasks + (block_n / WAVE) - 1) / (block_n / WAVE);
         const uint32_t grid = (uint32_t)(want < cus ? (want ? want : 1) : cus);
         if (known_kind == 2u) { g_grid = grid; g_block = block_n; }
@@ -2076,13 +2167,15 @@ int launch_consensus(const TaxDev& tax, const HitsDev& hits, int strategy, blu_r
                      int num_cus, uint32_t* worklist, uint32_t* work_count, uint32_t* kind_dev, uint32_t known_kind) {
     (void)device;
     if (hits.n_queries == 0) return BLU_OK;
-    const int layout = hits.packed ? 2 : (hits.pident_milli ? 1 : 0);
+    const int layout = hits.packed64 ? 3 : (hits.packed ? 2 : (hits.pident_milli ? 1 : 0));
     hipStream_t s = (hipStream_t)stream;
     if (strategy == BLU_RELAXED) {
+        if (layout == 3) return launch_t<BLU_RELAXED, 3>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
         if (layout == 2) return launch_t<BLU_RELAXED, 2>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
         if (layout == 1) return launch_t<BLU_RELAXED, 1>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
         return launch_t<BLU_RELAXED, 0>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
     }
+    if (layout == 3) return launch_t<BLU_CAUTIOUS, 3>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
     if (layout == 2) return launch_t<BLU_CAUTIOUS, 2>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
     if (layout == 1) return launch_t<BLU_CAUTIOUS, 1>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);
     return launch_t<BLU_CAUTIOUS, 0>(tax, hits, out, s, num_cus, worklist, work_count, kind_dev, known_kind);

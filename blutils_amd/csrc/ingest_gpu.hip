@@ -954,14 +954,19 @@ __device__ __forceinline__ bool milli_of(double p, uint32_t* k_out) {
     return ok;
 }
 // 16-byte side records of the packed layout (include/blu_consensus.h: blu_hits.packed) straight from the ingest's columns
+// (what blu_hits_pack builds from engine row ids, pack_kernel.hip, here straight from the taxonomy rows of the join: word 1 =
+// milli-percent perc_identity | shape hint of the row << 17)
 __global__ void pack_side_records(const uint32_t* __restrict__ desc_row, const double* __restrict__ pid, const int32_t* __restrict__ aln,
                                   const uint32_t* __restrict__ acc, uint64_t n, const uint32_t* __restrict__ fwd, uint64_t n_tax,
-                                  uint4* __restrict__ rec, uint32_t* __restrict__ inexact) {
+                                  const uint16_t* __restrict__ hint_of_pos, uint4* __restrict__ rec, uint32_t* __restrict__ inexact) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t k;
-    if (!milli_of(pid[i], &k)) *inexact = 1u;
-    rec[i] = make_uint4(engine_row_of(desc_row[i], fwd, n_tax), k, (uint32_t)aln[i], acc[i]);
+    if (!milli_of(pid[i], &k) || k >= BLU_PACKED_PIDENT_LIMIT) *inexact = 1u;
+    const uint32_t row = engine_row_of(desc_row[i], fwd, n_tax);
+    const uint32_t pos = row & ((1u << BLU_ROW_BITS) - 1u);
+    const uint32_t hint = (row != ROW_NO_TAXID && pos < n_tax) ? (uint32_t)hint_of_pos[pos] : 0u;
+    rec[i] = make_uint4(row, (k & BLU_KTHR_NEVER) | (hint << BLU_KTHR_BITS), (uint32_t)aln[i], acc[i]);
 }
 __global__ void to_engine_rows(const uint32_t* __restrict__ desc_row, uint64_t n, const uint32_t* __restrict__ fwd, uint64_t n_tax,
                                uint32_t* __restrict__ rows) {
@@ -1053,7 +1058,7 @@ int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_
         if (!packed) (void)hipGetLastError();
         if (packed) {
             hipLaunchKernelGGL(pack_side_records, grid(n), dim3(256), 0, 0, dev.tax_desc_row, dev.pident, dev.align_len, dev.acc_rank, n,
-                               d_fwd, n_tax, d_rec, d_flag);
+                               d_fwd, n_tax, tax->d_hint_of_pos, d_rec, d_flag);
             HIPCHK(hipMemcpy(&inexact, d_flag, 4, hipMemcpyDeviceToHost));
             if (inexact) { (void)hipFree(d_rec); d_rec = nullptr; packed = false; }
         }

@@ -1,0 +1,149 @@
+// blu_hits_pack / blu_hits_pack64 (include/blu_consensus.h): the side records of the packed hit-table layouts from the
+// four non-bit-score columns.  An ingest-time pass (like the taxid join that produced tax_row, mod.rs:72-76): it moves
+// values next to each other and adds the shape hint — a function of the joined taxonomy row — and computes nothing of
+// the consensus.  HBM-bound copy work: one 16- or 24-byte record written per hit.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "blu_internal.h"
+
+namespace blu {
+namespace {
+
+// k = round(p * 1000) when fl(k / 1000.0) == p bit for bit (the milli-percent encoding is lossless exactly then)
+__host__ __device__ inline bool exact_milli(double p, uint32_t* k_out) {
+    bool ok = p >= 0.0 && p < 4.0e6;
+    uint32_t k = 0;
+    if (ok) {
+        k = (uint32_t)(p * 1000.0 + 0.5);
+        const double back = (double)k / 1000.0;
+        uint64_t a, b;
+        memcpy(&a, &back, 8); memcpy(&b, &p, 8);
+        ok = a == b;
+    }
+    *k_out = k;
+    return ok;
+}
+
+__host__ __device__ inline uint32_t hint_of(uint32_t engine_row, const uint16_t* hint_of_pos, uint64_t n_tax) {
+    const uint32_t pos = engine_row & ((1u << BLU_ROW_BITS) - 1u);
+    return (engine_row != BLU_UNMATCHED_TAXID && pos < n_tax) ? (uint32_t)hint_of_pos[pos] : 0u;
+}
+
+// one record; returns false when the 16-byte layout cannot hold the row's perc_identity
+__host__ __device__ inline bool make16(uint32_t row, const double* pid, const uint32_t* pm, uint64_t i, const uint16_t* hint_of_pos,
+                                       uint64_t n_tax, uint32_t* w1) {
+    uint32_t k;
+    bool ok = true;
+    if (pm) k = pm[i];
+    else ok = exact_milli(pid[i], &k);
+    ok = ok && k < BLU_PACKED_PIDENT_LIMIT;
+    *w1 = (k & BLU_KTHR_NEVER) | (hint_of(row, hint_of_pos, n_tax) << BLU_KTHR_BITS);
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void pack16_kernel(const uint32_t* __restrict__ tax_row, const double* __restrict__ pid,
+                                                      const uint32_t* __restrict__ pm, const int32_t* __restrict__ aln,
+                                                      const uint32_t* __restrict__ acc, uint64_t n, const uint16_t* __restrict__ hint_of_pos,
+                                                      uint64_t n_tax, uint4* __restrict__ out, uint32_t* __restrict__ bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t row = tax_row[i];
+    uint32_t w1;
+    if (!make16(row, pid, pm, i, hint_of_pos, n_tax, &w1)) *bad = 1u;
+    out[i] = make_uint4(row, w1, (uint32_t)aln[i], acc[i]);
+}
+
+__global__ __launch_bounds__(256) void pack24_kernel(const uint32_t* __restrict__ tax_row, const double* __restrict__ pid,
+                                                      const uint32_t* __restrict__ pm, const int32_t* __restrict__ aln,
+                                                      const uint32_t* __restrict__ acc, uint64_t n, const uint16_t* __restrict__ hint_of_pos,
+                                                      uint64_t n_tax, uint2* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t row = tax_row[i];
+    const double p = pid ? pid[i] : (double)pm[i] / 1000.0;   // (the engine's own conversion of a milli-percent value)
+    out[3 * i] = make_uint2(row, hint_of(row, hint_of_pos, n_tax) << BLU_KTHR_BITS);
+    out[3 * i + 1] = make_uint2((uint32_t)aln[i], acc[i]);
+    out[3 * i + 2] = make_uint2((uint32_t)__double2loint(p), (uint32_t)__double2hiint(p));
+}
+
+int check_args(const blu_taxonomy* tax, const blu_hits* c, const void* out) {
+    if (!tax || !c) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    if (c->n_hits == 0) return BLU_OK;
+    if (!out || !c->tax_row || !c->align_len || !c->acc_rank || ((c->pident != nullptr) + (c->pident_milli != nullptr) != 1)) {
+        set_error("blu_hits_pack needs tax_row, align_len, acc_rank and one of pident / pident_milli"); return BLU_ERR_INVALID_ARG;
+    }
+    if (c->on_device && tax->device < 0) { set_error("host-only taxonomy handle: device columns need a HIP device"); return BLU_ERR_NO_DEVICE; }
+    return BLU_OK;
+}
+
+}  // namespace
+}  // namespace blu
+
+using namespace blu;
+
+extern "C" {
+
+int blu_hits_pack(const blu_taxonomy* tax, const blu_hits* c, uint32_t* out, void* stream) {
+    int rc = check_args(tax, c, out);
+    if (rc != BLU_OK || c->n_hits == 0) return rc;
+    const uint64_t n = c->n_hits;
+    if (!c->on_device) {
+        bool ok = true;
+        for (uint64_t i = 0; i < n; ++i) {
+            uint32_t w1;
+            ok &= make16(c->tax_row[i], c->pident, c->pident_milli, i, tax->hint_of_pos.data(), tax->n_tax, &w1);
+            out[4 * i] = c->tax_row[i]; out[4 * i + 1] = w1; out[4 * i + 2] = (uint32_t)c->align_len[i]; out[4 * i + 3] = c->acc_rank[i];
+        }
+        if (!ok) { set_error("blu_hits_pack: a perc_identity is not an exact milli-percent value below 131.071 (use the column layouts or blu_hits_pack64)"); return BLU_ERR_INVALID_ARG; }
+        return BLU_OK;
+    }
+    if ((uintptr_t)out & 15u) { set_error("packed records must be 16-byte aligned"); return BLU_ERR_INVALID_ARG; }
+    if (hipSetDevice(tax->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", tax->device); return BLU_ERR_NO_DEVICE; }
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* d_bad = nullptr;
+    uint32_t bad = 0;
+    if (hipMalloc((void**)&d_bad, 4) != hipSuccess) { set_error("hipMalloc failed"); return BLU_ERR_ALLOC; }
+    hipError_t e = hipMemsetAsync(d_bad, 0, 4, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->tax_row, c->pident, c->pident_milli, c->align_len,
+                           c->acc_rank, n, tax->d_hint_of_pos, tax->n_tax, reinterpret_cast<uint4*>(out), d_bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) { set_error("blu_hits_pack: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
+    if (bad) { set_error("blu_hits_pack: a perc_identity is not an exact milli-percent value below 131.071 (use the column layouts or blu_hits_pack64)"); return BLU_ERR_INVALID_ARG; }
+    return BLU_OK;
+}
+
+int blu_hits_pack64(const blu_taxonomy* tax, const blu_hits* c, uint32_t* out, void* stream) {
+    int rc = check_args(tax, c, out);
+    if (rc != BLU_OK || c->n_hits == 0) return rc;
+    const uint64_t n = c->n_hits;
+    if (!c->on_device) {
+        for (uint64_t i = 0; i < n; ++i) {
+            const double p = c->pident ? c->pident[i] : (double)c->pident_milli[i] / 1000.0;
+            uint64_t bits;
+            memcpy(&bits, &p, 8);
+            uint32_t* r = out + 6 * i;
+            r[0] = c->tax_row[i]; r[1] = hint_of(c->tax_row[i], tax->hint_of_pos.data(), tax->n_tax) << BLU_KTHR_BITS;
+            r[2] = (uint32_t)c->align_len[i]; r[3] = c->acc_rank[i]; r[4] = (uint32_t)bits; r[5] = (uint32_t)(bits >> 32);
+        }
+        return BLU_OK;
+    }
+    if ((uintptr_t)out & 7u) { set_error("packed64 records must be 8-byte aligned"); return BLU_ERR_INVALID_ARG; }
+    if (hipSetDevice(tax->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", tax->device); return BLU_ERR_NO_DEVICE; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pack24_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->tax_row, c->pident, c->pident_milli, c->align_len,
+                       c->acc_rank, n, tax->d_hint_of_pos, tax->n_tax, reinterpret_cast<uint2*>(out));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_error("blu_hits_pack64: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
+    return BLU_OK;
+}
+
+}  // extern "C"

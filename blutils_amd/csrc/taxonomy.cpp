@@ -279,8 +279,15 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         return a < b;
     });
     tax->pos_of.assign(n, 0);
-    for (uint64_t i = 0; i < n; ++i)   // engine row id: sorted position | lineage length << BLU_ROW_BITS
-        tax->pos_of[order[i]] = (uint32_t)i | ((L[(size_t)order[i] * stride] & 0xFF) << BLU_ROW_BITS);
+    tax->hint_of_pos.assign(std::max<uint64_t>(n, 1), 0);
+    for (uint64_t i = 0; i < n; ++i) {  // engine row id: sorted position | lineage length << BLU_ROW_BITS
+        const uint32_t hdr = L[(size_t)order[i] * stride];
+        tax->pos_of[order[i]] = (uint32_t)i | ((hdr & 0xFF) << BLU_ROW_BITS);
+        // shape hint of the packed layout's side records: shape id + 1 in 15 bits, 0 = none (a bad lineage, or a shape id that
+        // does not fit: the engine then reads the shape from the row, one memory round trip later)
+        const uint32_t shape = hdr >> 8;
+        tax->hint_of_pos[i] = ((hdr & 0xFF) != 0 && shape + 1 < (1u << BLU_HINT_BITS)) ? (uint16_t)(shape + 1) : (uint16_t)0;
+    }
     std::vector<uint32_t> lin_sorted((size_t)n * stride);   // host layout (hdr, nodes), sorted: for the LCP pass below
     for (uint64_t i = 0; i < n; ++i)
         memcpy(&lin_sorted[(size_t)i * stride], L + (size_t)order[i] * stride, stride * sizeof(uint32_t));
@@ -330,6 +337,14 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
             }
             dev_kthr[k] = it->second;
         }
+    }
+    // One word per level with everything the integer level tests and the record need: that threshold (18 bits) | canonical
+    // rank code (10 bits) << 18 | "max_allowed_rank can never equal a parsed rank" (BLU_MAR_NEVER_EQUAL) << 28 — the
+    // max-allowed-rank code of a level is its own rank code or that constant (see h_codes above), so one bit says which.
+    for (size_t k = 0; k < (size_t)tax->n_shapes * tax->sc; ++k) {
+        const uint32_t code = tax->h_codes[k];
+        const uint32_t rank = code & 0xFFFF, mar = code >> 16;
+        dev_kthr[k] |= (rank << BLU_LVL_RANK_SHIFT) | ((mar == BLU_MAR_NEVER_EQUAL ? 1u : 0u) << BLU_LVL_NEVER_SHIFT);
     }
     if (cutvals.size() >= (1u << BLU_PACK_CUT_BITS)) { delete tax; set_error("more than %u distinct cutoff values", (1u << BLU_PACK_CUT_BITS) - 1); return BLU_ERR_INVALID_ARG; }
     if (cutvals.empty()) cutvals.push_back(0.0);
@@ -425,12 +440,14 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         if (e == hipSuccess) e = hipMemcpy(tax->d_lcp8, lcp8.data(), lcp8.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_rmq, rmq.data(), rmq.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_cutvals, cutvals.data(), b_cut, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_hint_of_pos, tax->hint_of_pos.size() * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMemcpy(tax->d_hint_of_pos, tax->hint_of_pos.data(), tax->hint_of_pos.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             set_error("HIP error while uploading the taxonomy: %s", hipGetErrorString(e));
             blu_taxonomy_destroy(tax);
             return BLU_ERR_HIP;
         }
-        tax->device_bytes = b_lin + lcp8.size() + rmq.size() + b_cut + 2 * b_codes;
+        tax->device_bytes = b_lin + lcp8.size() + rmq.size() + b_cut + 2 * b_codes + tax->hint_of_pos.size() * sizeof(uint16_t);
     }
     *out = tax;
     return BLU_OK;
@@ -446,6 +463,7 @@ void blu_taxonomy_destroy(blu_taxonomy* tax) {
         if (tax->d_cutvals) (void)hipFree(tax->d_cutvals);
         if (tax->d_codes) (void)hipFree(tax->d_codes);
         if (tax->d_kthr) (void)hipFree(tax->d_kthr);
+        if (tax->d_hint_of_pos) (void)hipFree(tax->d_hint_of_pos);
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
         if (tax->ws_count) (void)hipFree(tax->ws_count);
         if (tax->ws_kind_host) (void)hipHostFree(tax->ws_kind_host);

@@ -154,25 +154,64 @@ class Taxonomy:
             pass
 
 
-def pack_records(tax_row, pident_milli, align_len, acc_rank) -> np.ndarray:
-    """[n, 4] uint32 side records {tax_row, pident_milli, align_len, acc_rank} of the packed layout (ABI v3)."""
-    cols = [np.ascontiguousarray(c) for c in (tax_row, pident_milli, align_len, acc_rank)]
-    cols = [c.view(np.uint32) if c.dtype == np.int32 else c.astype(np.uint32) for c in cols]
-    return np.ascontiguousarray(np.stack(cols, axis=1))
+def _u32(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.int32 else np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def pack_records(tax: "Taxonomy", tax_row, pident_milli, align_len, acc_rank, pident=None, wide: bool = False) -> np.ndarray:
+    """blu_hits_pack / blu_hits_pack64 on host arrays: the [n, 4] (or, wide, [n, 6]) uint32 side records of the packed
+    layouts (include/blu_consensus.h) — {tax_row, pident_milli | shape hint << 17, align_len, acc_rank} (+ the f64
+    perc_identity for the wide form).  tax_row: ENGINE row ids."""
+    tx, aln, ac = _u32(tax_row), np.ascontiguousarray(align_len, dtype=np.int32), _u32(acc_rank)
+    pm = _u32(pident_milli) if pident_milli is not None else None
+    pid = np.ascontiguousarray(pident, dtype=np.float64) if pident is not None else None
+    n = len(tx)
+    out = np.zeros((n, 6 if wide else 4), dtype=np.uint32)
+    cols = N.Hits(None, tx.ctypes.data, pid.ctypes.data if pid is not None else None, aln.ctypes.data, ac.ctypes.data, None, n, 0, 0, 0,
+                  pm.ctypes.data if pm is not None else None, None, None)
+    fn = N.lib().blu_hits_pack64 if wide else N.lib().blu_hits_pack
+    rc = fn(tax.handle, C.byref(cols), out.ctypes.data, None)
+    if rc != N.BLU_OK:
+        raise N.BluError(rc, "blu_hits_pack")
+    return out
+
+
+def pack_hits_device(tax: "Taxonomy", hits: dict, wide: bool = False):
+    """blu_hits_pack / blu_hits_pack64 on torch CUDA columns (keys tax_row, align_len, acc_rank and pident_milli or pident):
+    the int32 tensor of 4 (wide: 6) words per hit that goes into `packed` / `packed64`."""
+    import torch
+    n = hits["tax_row"].numel()
+    out = torch.empty((6 if wide else 4) * n, dtype=torch.int32, device=hits["tax_row"].device)
+    pm, pid = hits.get("pident_milli"), hits.get("pident")
+    if pm is not None:
+        pid = None
+    for k in ("tax_row", "align_len", "acc_rank"):
+        assert hits[k].is_cuda and hits[k].is_contiguous() and hits[k].dtype == torch.int32, k
+    cols = N.Hits(None, hits["tax_row"].data_ptr(), pid.data_ptr() if pid is not None else None, hits["align_len"].data_ptr(),
+                  hits["acc_rank"].data_ptr(), None, n, 0, 1, 0, pm.data_ptr() if pm is not None else None, None, None)
+    fn = N.lib().blu_hits_pack64 if wide else N.lib().blu_hits_pack
+    rc = fn(tax.handle, C.byref(cols), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if rc != N.BLU_OK:
+        raise N.BluError(rc, "blu_hits_pack")
+    return out
 
 
 def run_consensus_host(tax: Taxonomy, seg_off, bitscore, tax_row, pident, align_len, acc_rank,
-                       strategy: str = "relaxed", pident_milli=None, packed: bool = False) -> np.ndarray:
+                       strategy: str = "relaxed", pident_milli=None, packed=False) -> np.ndarray:
     """Host buffers in, host records out; the library stages them over PCIe.  tax_row: ENGINE row ids.
     pident_milli (uint32, perc_identity * 1000) replaces the f64 `pident` column when given (pass pident=None);
-    packed=True (needs pident_milli) hands the four non-bit-score columns over as 16-byte records."""
+    packed=True hands the four non-bit-score columns over as 16-byte records built by blu_hits_pack (pident_milli, or an
+    f64 column of exact milli-percent values); packed="wide": the 24-byte records of blu_hits_pack64 (any f64)."""
     if packed:
         seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
         bs = np.ascontiguousarray(bitscore, dtype=np.int32)
-        rec = pack_records(tax_row, pident_milli, align_len, acc_rank)
+        wide = packed == "wide"
+        rec = pack_records(tax, tax_row, pident_milli, align_len, acc_rank, pident=pident if pident_milli is None else None, wide=wide)
         nq, nh = len(seg) - 1, int(seg[-1])
-        assert rec.shape == (nh, 4) and rec.ctypes.data % 16 == 0
-        hits = N.Hits(bs.ctypes.data, None, None, None, None, seg.ctypes.data, nh, nq, 0, 0, None, rec.ctypes.data)
+        assert rec.shape == (nh, 6 if wide else 4) and rec.ctypes.data % 16 == 0
+        hits = N.Hits(bs.ctypes.data, None, None, None, None, seg.ctypes.data, nh, nq, 0, 0, None, None if wide else rec.ctypes.data,
+                      rec.ctypes.data if wide else None)
         params = N.RunParams(N.STRATEGY[strategy], 0, None)
         out = np.zeros(nq, dtype=RESULT_DTYPE)
         rc = N.lib().blu_consensus_run(tax.handle, C.byref(hits), C.byref(params), out.ctypes.data)
@@ -195,7 +234,7 @@ def run_consensus_host(tax: Taxonomy, seg_off, bitscore, tax_row, pident, align_
     nh = int(seg[-1])
     assert len(bs) == nh and len(tx) == nh and len(pid if pm is None else pm) == nh and len(aln) == nh and len(ac) == nh
     hits = N.Hits(bs.ctypes.data, tx.ctypes.data, pid.ctypes.data if pm is None else None, aln.ctypes.data, ac.ctypes.data,
-                  seg.ctypes.data, nh, nq, 0, 0, pm.ctypes.data if pm is not None else None, None)
+                  seg.ctypes.data, nh, nq, 0, 0, pm.ctypes.data if pm is not None else None, None, None)
     params = N.RunParams(N.STRATEGY[strategy], 0, None)
     out = np.zeros(nq, dtype=RESULT_DTYPE)
     rc = N.lib().blu_consensus_run(tax.handle, C.byref(hits), C.byref(params), out.ctypes.data)
@@ -230,7 +269,7 @@ def run_consensus_multi(taxes: Sequence[Taxonomy], seg_off, bitscore, tax_row, p
     ac = ac.view(np.uint32) if ac.dtype == np.int32 else np.ascontiguousarray(ac, dtype=np.uint32)
     nq, nh = len(seg) - 1, int(seg[-1])
     hits = N.Hits(bs.ctypes.data, tx.ctypes.data, pid.ctypes.data if pm is None else None, aln.ctypes.data, ac.ctypes.data,
-                  seg.ctypes.data, nh, nq, 0, 0, pm.ctypes.data if pm is not None else None, None)
+                  seg.ctypes.data, nh, nq, 0, 0, pm.ctypes.data if pm is not None else None, None, None)
     params = N.RunParams(N.STRATEGY[strategy], 0, None)
     out = np.zeros(nq, dtype=RESULT_DTYPE)
     handles = (C.c_void_p * len(taxes))(*[t.handle for t in taxes])
@@ -253,8 +292,9 @@ def run_consensus_device(tax: Taxonomy, hits: dict, out, strategy: str = "relaxe
     nh = hits["bitscore"].numel()
     milli = hits.get("pident_milli") is not None
     packed = hits.get("packed") is not None
-    if packed:     # 16-byte side records {tax_row, pident_milli, align_len, acc_rank} next to the bit-score column
-        want = (("seg_off", torch.int64), ("bitscore", torch.int32), ("packed", torch.int32))
+    wide = hits.get("packed64") is not None
+    if packed or wide:     # side records next to the bit-score column (blu_hits_pack / blu_hits_pack64)
+        want = (("seg_off", torch.int64), ("bitscore", torch.int32), ("packed64" if wide else "packed", torch.int32))
     else:
         want = (("seg_off", torch.int64), ("bitscore", torch.int32), ("tax_row", torch.int32),
                 ("pident_milli", torch.int32) if milli else ("pident", torch.float64), ("align_len", torch.int32),
@@ -265,14 +305,18 @@ def run_consensus_device(tax: Taxonomy, hits: dict, out, strategy: str = "relaxe
     assert out.is_cuda and out.is_contiguous() and out.numel() * out.element_size() >= 32 * nq
     if stream is None:
         stream = torch.cuda.current_stream().cuda_stream
-    if packed:
+    if wide:
+        assert hits["packed64"].numel() == 6 * nh and hits["packed64"].data_ptr() % 8 == 0
+        h = N.Hits(hits["bitscore"].data_ptr(), None, None, None, None, hits["seg_off"].data_ptr(), nh, nq, 1, 0, None, None,
+                   hits["packed64"].data_ptr())
+    elif packed:
         assert hits["packed"].numel() == 4 * nh and hits["packed"].data_ptr() % 16 == 0
         h = N.Hits(hits["bitscore"].data_ptr(), None, None, None, None, hits["seg_off"].data_ptr(), nh, nq, 1, 0, None,
-                   hits["packed"].data_ptr())
+                   hits["packed"].data_ptr(), None)
     else:
         h = N.Hits(hits["bitscore"].data_ptr(), hits["tax_row"].data_ptr(), None if milli else hits["pident"].data_ptr(),
                    hits["align_len"].data_ptr(), hits["acc_rank"].data_ptr(), hits["seg_off"].data_ptr(), nh, nq, 1, 0,
-                   hits["pident_milli"].data_ptr() if milli else None, None)
+                   hits["pident_milli"].data_ptr() if milli else None, None, None)
     params = N.RunParams(N.STRATEGY[strategy], 0, stream)
     rc = N.lib().blu_consensus_run(tax.handle, C.byref(h), C.byref(params), out.data_ptr())
     if rc != N.BLU_OK:

@@ -245,12 +245,27 @@ class SynthHits:
     n_hits: int = 0
     pident_milli: "object" = None   # int32: perc_identity * 1000 (the generator draws 3-decimal values)
 
-    def as_dict(self, layout: str = "f64"):
-        """layout "f64": the canonical 24 B/hit columns; "milli": pident as milli-percent uint32, 20 B/hit."""
+    def as_dict(self, layout: str = "f64", tax=None):
+        """layout "f64": the canonical 24 B/hit columns; "milli": pident as milli-percent uint32, 20 B/hit; "packed" /
+        "packed64": the bit-score column + the side records blu_hits_pack / blu_hits_pack64 build from the columns (tax =
+        the engine.Taxonomy whose row ids self.tax_row holds; without it the 16-byte records are put together here, with
+        no shape hint — a form the engine also takes)."""
         d = {"seg_off": self.seg_off, "bitscore": self.bitscore, "tax_row": self.tax_row,
              "align_len": self.align_len, "acc_rank": self.acc_rank}
-        if layout == "packed":   # bit-score column + 16-byte side records {tax_row, pident_milli, align_len, acc_rank}
+        if layout in ("packed", "packed64"):
             import torch
+            from . import _native
+            if layout == "packed" and not hasattr(_native.lib(), "blu_hits_pack"):
+                tax = None                               # (an A/B library of an older ABI: records without hints)
+            if tax is not None and self.tax_row.is_cuda:
+                from . import engine
+                cols = dict(d)
+                if layout == "packed64" and self.pident is not None:
+                    cols["pident"] = self.pident
+                else:
+                    cols["pident_milli"] = self.pident_milli
+                return {"seg_off": self.seg_off, "bitscore": self.bitscore, layout: engine.pack_hits_device(tax, cols, wide=layout == "packed64")}
+            assert layout == "packed", "packed64 records are built by blu_hits_pack64: pass tax="
             rec = torch.stack([self.tax_row, self.pident_milli, self.align_len, self.acc_rank], dim=1).contiguous().reshape(-1)
             return {"seg_off": self.seg_off, "bitscore": self.bitscore, "packed": rec}
         if layout == "milli":

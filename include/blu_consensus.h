@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BLU_ABI_VERSION 3u
+#define BLU_ABI_VERSION 4u
 #define BLU_UNMATCHED_TAXID 0xFFFFFFFFu /* hit whose subject_taxid is not in the taxonomy (left join miss, mod.rs:72-76) */
 #define BLU_MAX_DEPTH 64u               /* level_mask is 64 bits wide */
 #define BLU_ROW_BITS 25u                /* engine row id = sorted position | lineage length << 25: at most 2^25 taxids */
@@ -104,14 +104,27 @@ typedef struct blu_hits {
                                   text has at most 3 decimals (BLAST outfmt 6 prints %.3f): k = perc_identity * 1000
                                   as an exact integer.  The engine rebuilds the f64 the reference's parser produces,
                                   the correctly rounded k / 1000, for the few rows that need it.  20 B/hit instead of
-                                  24.  Exactly one of pident / pident_milli / packed is non-NULL. */
+                                  24. */
     const uint32_t* packed;    /* [n_hits][4] or NULL (ABI v3).  The four non-bit-score values of a hit side by side,
-                                  16 bytes per hit: {tax_row, pident_milli, align_len, acc_rank}; tax_row, pident,
-                                  pident_milli, align_len and acc_rank are then ignored (may be NULL).  Same 20 B/hit
-                                  as the milli-percent columns, but the engine — which reads those four values for the
-                                  top-scoring rows only — finds a row's values in ONE memory line instead of four.
-                                  16-byte aligned. */
+                                  16 bytes per hit: {tax_row, pident_milli | shape hint << 17, align_len, acc_rank};
+                                  tax_row, pident, pident_milli, align_len and acc_rank are then ignored (may be NULL).
+                                  Same 20 B/hit as the milli-percent columns, but the engine — which reads those four
+                                  values for the top-scoring rows only — finds a row's values in ONE memory line instead
+                                  of four.  16-byte aligned.  Built by blu_hits_pack (ABI v4): pident_milli must be below
+                                  BLU_PACKED_PIDENT_LIMIT (131.071 %; larger identities go in the column layouts), and
+                                  the bits above it carry a hint for the engine — the lineage shape of the hit's taxonomy
+                                  row + 1, a function of the joined taxid like the row id itself — which lets it ask for
+                                  the per-level tables together with the reference row instead of after it.  A hint of 0
+                                  (records put together by hand) or a wrong one costs a memory round trip, never a
+                                  result: the engine checks it against the row. */
+    const uint32_t* packed64;  /* [n_hits][6] or NULL (ABI v4).  The same for perc_identity values that are not exact
+                                  milli-percent: 24 bytes per hit {tax_row, shape hint << 17, align_len, acc_rank,
+                                  pident f64 (low word, high word)}, 8-byte aligned; built by blu_hits_pack64.  28 B/hit
+                                  with the bit-score column.  Exactly one of pident / pident_milli / packed / packed64
+                                  is non-NULL. */
 } blu_hits;
+
+#define BLU_PACKED_PIDENT_LIMIT 131071u /* packed layout: pident_milli < this (17 bits, the top value is the engine's "never") */
 
 typedef struct blu_run_params {
     int32_t strategy; /* enum blu_strategy */
@@ -196,6 +209,15 @@ int blu_taxonomy_row_map(const blu_taxonomy* tax, uint32_t* out_map, uint32_t* o
  * (worklist and its counters) is reused from run to run. */
 int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_run_params* params,
                       blu_result* out);
+
+/* The side records of the packed layouts from the four columns (an ingest-time pass, like the join that produced
+ * tax_row): `columns` holds tax_row (engine row ids), align_len, acc_rank and pident_milli or pident, n_hits and
+ * on_device (1: device pointers on the handle's GPU, out too; the kernel runs on `stream` and the call returns after
+ * it has finished — it reports values the layout cannot hold).  blu_hits_pack writes 4 words per hit and fails with
+ * BLU_ERR_INVALID_ARG if a perc_identity is not an exact milli-percent value below BLU_PACKED_PIDENT_LIMIT;
+ * blu_hits_pack64 writes 6 words per hit and takes any f64 (or milli-percent column, converted as the engine would). */
+int blu_hits_pack(const blu_taxonomy* tax, const blu_hits* columns, uint32_t* packed_out, void* stream);
+int blu_hits_pack64(const blu_taxonomy* tax, const blu_hits* columns, uint32_t* packed64_out, void* stream);
 
 /* One host table over several GPUs: `taxes[0..n_tax_handles)` are handles of the SAME taxonomy and cutoff
  * configuration on different devices (the same device twice is allowed).  Queries are cut into contiguous ranges

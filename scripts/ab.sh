@@ -7,7 +7,7 @@ REPS=${REPS:-3}
 for r in $(seq $REPS); do
 for v in "$@"; do
   if [ "$v" = "base" ]; then unset BLU_CONSENSUS_LIB; else export BLU_CONSENSUS_LIB=$GRAFT_REPO_ROOT/blutils_amd/lib/exp/lib_$v.so; fi
-  timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-parity-gate --no-cpu-baseline $AB_ARGS 2>/dev/null | python3 -c "
+  timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-parity-gate --no-cpu-baseline --no-secondary $AB_ARGS 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', '%.4f' % d['roofline']['kernel_ms'])"
 done

@@ -6,7 +6,7 @@ REPS=${REPS:-3}
 for r in $(seq $REPS); do
 for v in "$@"; do
   if [ "$v" = "base" ]; then unset BLU_CONSENSUS_LIB; else export BLU_CONSENSUS_LIB=$PWD/blutils_amd/lib/exp/lib_$v.so; fi
-  python bench.py --steps 10 --warmup 2 --no-parity-gate --no-cpu-baseline $EXP_BENCH_ARGS 2>/dev/null | python -c "
+  python bench.py --steps 10 --warmup 2 --no-parity-gate --no-cpu-baseline --no-secondary $EXP_BENCH_ARGS 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
 print('$v', '%.3f'%r['kernel_ms'])"

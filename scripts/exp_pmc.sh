@@ -8,9 +8,9 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 for v in "$@"; do
   if [ "$v" = "base" ]; then unset BLU_CONSENSUS_LIB; else export BLU_CONSENSUS_LIB=$GRAFT_REPO_ROOT/blutils_amd/lib/exp/lib_$v.so; fi
-  timeout -k 10 120 python3 bench.py --steps 10 --warmup 2 --no-parity-gate --no-cpu-baseline $EXP_BENCH_ARGS > "$out/$v.json" 2> "$out/$v.log" || { echo "$v bench failed"; continue; }
+  timeout -k 10 120 python3 bench.py --steps 10 --warmup 2 --no-parity-gate --no-cpu-baseline --no-secondary $EXP_BENCH_ARGS > "$out/$v.json" 2> "$out/$v.log" || { echo "$v bench failed"; continue; }
   timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --kernel-include-regex "blu_consensus_stream" --output-format csv -d "$out/pmc_$v" -- \
-     python3 bench.py --steps 3 --warmup 1 --no-parity-gate --no-cpu-baseline $EXP_BENCH_ARGS > /dev/null 2> "$out/pmc_$v.log"
+     python3 bench.py --steps 3 --warmup 1 --no-parity-gate --no-cpu-baseline --no-secondary $EXP_BENCH_ARGS > /dev/null 2> "$out/pmc_$v.log"
   python3 - "$out" "$v" <<'PY'
 import csv, glob, json, sys, collections
 out, v = sys.argv[1], sys.argv[2]

@@ -11,7 +11,7 @@ i=0
 for grp in "$@"; do
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $grp --kernel-include-regex "blu_" --output-format csv -d "$out/pass$i" -- \
-     python3 bench.py --steps 3 --warmup 1 --no-parity-gate --no-cpu-baseline $PMC_BENCH_ARGS > "$out/pass$i.json" 2> "$out/pass$i.log"
+     python3 bench.py --steps 3 --warmup 1 --no-parity-gate --no-cpu-baseline --no-secondary $PMC_BENCH_ARGS > "$out/pass$i.json" 2> "$out/pass$i.log"
   echo "pass $i ($grp) rc=$?"
 done
 python3 scripts/pmc_summary.py "$out"

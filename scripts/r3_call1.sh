@@ -10,7 +10,7 @@ BLU_CONSENSUS_LIB=$PWD/blutils_amd/lib/exp/lib_stamps.so timeout -k 10 200 pytho
 BLU_CONSENSUS_LIB=$PWD/blutils_amd/lib/exp/lib_stamps.so timeout -k 10 200 python3 scripts/stamps.py --queries 1250000 > $out/stamps_slice.txt 2>&1
 timeout -k 10 300 scripts/exp_pmc.sh $out/pmc base refnt > $out/exp_pmc.txt 2>&1
 for w in "--top-group zymo" "--config C5" "--pident f64" "--config C2 --graph" "--config C2"; do
-  n=$(echo $w | tr -d ' -'); timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-parity-gate --no-cpu-baseline $w > $out/w_$n.json 2> $out/w_$n.err
+  n=$(echo $w | tr -d ' -'); timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-parity-gate --no-cpu-baseline --no-secondary $w > $out/w_$n.json 2> $out/w_$n.err
 done
 tail -n 20 $out/*.txt
 for f in $out/w_*.json; do python3 -c "

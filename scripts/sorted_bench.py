@@ -19,10 +19,10 @@ def timeit(d):
     for _ in range(5): engine.run_consensus_device(t, d, out)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / 5
-print("as generated      : %.3f ms" % timeit(hits.as_dict("packed")))
+print("as generated      : %.3f ms" % timeit(hits.as_dict("packed", tax=t)))
 order = torch.argsort(hits.bitscore.view(-1, 50), dim=1, descending=True, stable=True)
 order = (order + torch.arange(hits.n_queries, device="cuda").view(-1, 1) * 50).reshape(-1)
 for name in ("bitscore", "tax_row", "pident_milli", "align_len", "acc_rank"):
     setattr(hits, name, getattr(hits, name)[order].contiguous())
-print("sorted, best first: %.3f ms" % timeit(hits.as_dict("packed")))
+print("sorted, best first: %.3f ms" % timeit(hits.as_dict("packed", tax=t)))
 print("sorted, columns   : %.3f ms" % timeit(hits.as_dict("milli")))

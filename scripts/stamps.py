@@ -18,7 +18,7 @@ tax = synth.make_taxonomy(cfg["n_taxa"], seed, deep=cfg["deep"])
 t = engine.Taxonomy(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, taxon="custom", custom=CUSTOM, device=0)
 hits = synth.make_hits(tax, cfg["n_queries"], seed, cfg["hits_per_query"], zipf=cfg["zipf"], device="cuda", columns="milli", top_group=a.top_group)
 hits.tax_row = t.engine_rows(hits.tax_row).contiguous()
-hd = hits.as_dict("packed")
+hd = hits.as_dict("packed", tax=t)
 out = torch.zeros(32 * hits.n_queries, dtype=torch.uint8, device="cuda")
 for _ in range(2):
     engine.run_consensus_device(t, hd, out)

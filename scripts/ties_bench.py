@@ -16,7 +16,7 @@ def timeit(d):
     for _ in range(5): engine.run_consensus_device(t, d, out)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / 5
-print("geometric(0.35) top groups: %.3f ms" % timeit(hits.as_dict("packed")))
+print("geometric(0.35) top groups: %.3f ms" % timeit(hits.as_dict("packed", tax=t)))
 # make the top group larger: the top `g` rows of every query share the top score
 bs = hits.bitscore.clone().view(-1, 50)
 for g in (5, 10, 15, 20, 25, 30, 40, 50):
@@ -24,6 +24,6 @@ for g in (5, 10, 15, 20, 25, 30, 40, 50):
     top = b2.max(dim=1, keepdim=True).values
     b2[:, :g] = top
     hits.bitscore = b2.reshape(-1).contiguous()
-    ms = timeit(hits.as_dict("packed"))
+    ms = timeit(hits.as_dict("packed", tax=t))
     st = engine.records_from_tensor(out)["status"]
     print("top group >= %2d rows: %.3f ms  (%.0f Mq/s)" % (g, ms, hits.n_queries / ms / 1e3))

@@ -466,12 +466,25 @@ def test_packed_layout_gives_identical_records():
     t = _engine_tax(tax, "bacteria")
     dh.tax_row = t.engine_rows(dh.tax_row).contiguous()
     outs = []
-    for layout in ("milli", "packed"):
+    # "packed" without the handle: side records put together by hand, no shape hint (the engine then reads the shape from
+    # the row); with it: blu_hits_pack / blu_hits_pack64 on the device, hints included
+    for layout, tx in (("milli", None), ("packed", None), ("packed", t), ("packed64", t)):
         out = torch.zeros(32 * dh.n_queries, dtype=torch.uint8, device="cuda")
-        engine.run_consensus_device(t, dh.as_dict(layout), out, strategy="cautious")
+        engine.run_consensus_device(t, dh.as_dict(layout, tax=tx), out, strategy="cautious")
         torch.cuda.synchronize()
         outs.append(engine.records_from_tensor(out))
-    assert outs[0].tobytes() == outs[1].tobytes()
+    for o in outs[1:]:
+        assert outs[0].tobytes() == o.tobytes()
+    # a hint that names another shape (or none that exists) costs a round trip, never a result
+    hinted = dh.as_dict("packed", tax=t)
+    rec = hinted["packed"].view(-1, 4)
+    wrong = rec.clone()
+    wrong[:, 1] = (rec[:, 1] & 0x1FFFF) | (((rec[:, 1] >> 17) * 7 + 3) % 32768 << 17)
+    out = torch.zeros(32 * dh.n_queries, dtype=torch.uint8, device="cuda")
+    engine.run_consensus_device(t, {"seg_off": hinted["seg_off"], "bitscore": hinted["bitscore"], "packed": wrong.reshape(-1).contiguous()}, out,
+                                strategy="cautious")
+    torch.cuda.synchronize()
+    assert engine.records_from_tensor(out).tobytes() == outs[0].tobytes()
     # fixed lengths around every width, host pointers
     for hits_per_query in (7, 20, 30, 50, 100, 200, 400, 600):
         tax2 = synth.make_taxonomy(3000, 77)
@@ -484,6 +497,8 @@ def test_packed_layout_gives_identical_records():
         b = engine.run_consensus_host(t2, h2["seg_off"], h2["bitscore"], rows, None, h2["align_len"], h2["acc_rank"], "relaxed", pident_milli=milli,
                                       packed=True)
         assert a.tobytes() == b.tobytes(), hits_per_query
+        c = engine.run_consensus_host(t2, h2["seg_off"], h2["bitscore"], rows, h2["pident"], h2["align_len"], h2["acc_rank"], "relaxed", packed="wide")
+        assert a.tobytes() == c.tobytes(), hits_per_query
         _assert_records_equal(b, H.columnar(tax2, h2, "custom", "relaxed", H.CUSTOM_16S))
 
 
@@ -525,21 +540,35 @@ def test_extreme_column_values(hits):
     h["align_len"] = rng.choice(np.array([i32.min, -7, 0, 400, i32.max], dtype=np.int32), n)
     h["acc_rank"] = rng.choice(np.array([0, 1, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF], dtype=np.uint32), n).view(np.int32)
     rows = t.engine_rows(h["tax_row"])
-    # f64 layout
+    # f64 layouts: the five columns, and the 24-byte side records of blu_hits_pack64
     h["pident"] = rng.choice(np.array([-np.inf, -1.0, -0.0, 0.0, 5e-324, 66.667, 97.0, 100.0, 1e308, np.inf]), n)
     for strategy in ("relaxed", "cautious"):
-        _assert_records_equal(_run_host(t, h, strategy), H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S))
-    # packed layout: any u32 is a milli-percent value; the oracle reads the double k / 1000
+        exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S)
+        _assert_records_equal(_run_host(t, h, strategy), exp)
+        got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], strategy, packed="wide")
+        _assert_records_equal(got, exp)
+    # milli-percent column: any u32 is a milli-percent value; the oracle reads the double k / 1000.  The 16-byte side
+    # records hold values below BLU_PACKED_PIDENT_LIMIT (131.071 %): blu_hits_pack refuses the rest, up to that limit they
+    # give the column's records.
     milli = rng.choice(np.array([0, 1, 66667, 96999, 97000, 100000, 100001, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF], dtype=np.uint32), n)
     h["pident"] = milli.astype(np.float64) / 1000.0
     for strategy in ("relaxed", "cautious"):
         exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S)
         got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy,
-                                        pident_milli=milli, packed=True)
-        _assert_records_equal(got, exp)
-        got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy,
                                         pident_milli=milli)
         _assert_records_equal(got, exp)
+        with pytest.raises(N.BluError, match="milli-percent"):
+            engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy,
+                                      pident_milli=milli, packed=True)
+    small = rng.choice(np.array([0, 1, 66667, 96999, 97000, 100000, 100001, 131069, 131070], dtype=np.uint32), n)
+    h["pident"] = small.astype(np.float64) / 1000.0
+    for strategy in ("relaxed", "cautious"):
+        exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S)
+        got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy,
+                                        pident_milli=small, packed=True)
+        _assert_records_equal(got, exp)
+        got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], strategy, packed=True)
+        _assert_records_equal(got, exp)                                      # (an f64 column of exact milli-percent values packs as well)
 
 
 def test_more_distinct_cutoffs_than_the_lds_table_holds():

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     L = N.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.blu_abi_version() == 3
+    assert L.blu_abi_version() == 4
     hdr2 = open(os.path.join(ROOT, "include", "blu_pipeline.h")).read()
     declared2 = set(re.findall(r"\b(blu_[a-z0-9_]+)\s*\(", hdr2))
     assert declared2 == set(N.PIPELINE_EXPORTS)
