@@ -91,6 +91,8 @@ def lib() -> C.CDLL:
     L.blu_consensus_run.restype = C.c_int
     L.blu_consensus_run.argtypes = [C.c_void_p, C.POINTER(Hits), C.POINTER(RunParams), C.c_void_p]
     for name in ("blu_hits_pack", "blu_hits_pack64"):
+        if not hasattr(L, name):                 # (an A/B library of an older ABI: BLU_CONSENSUS_LIB, scripts/ab.sh)
+            continue
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [C.c_void_p, C.POINTER(Hits), C.c_void_p, C.c_void_p]
     L.blu_consensus_last_launch.restype = C.c_int

@@ -35,18 +35,26 @@ using namespace blu;
 // of them instead of launching the other table's kind.
 static uint32_t known_kind(const blu_taxonomy* tax, const void* seg_off, uint64_t n_queries) {
     // BLU_STREAM_KIND=ring | noring: that build for every table (tests: both builds must give the same records on any table)
+    uint32_t forced_kind = 0;
     if (const char* env = getenv("BLU_STREAM_KIND")) {
-        if (strcmp(env, "ring") == 0) return 1u;
-        if (strcmp(env, "noring") == 0) return 2u;
+        if (strcmp(env, "ring") == 0) forced_kind = 1u;
+        if (strcmp(env, "noring") == 0) forced_kind = 2u;
     }
     const uint64_t call = __atomic_fetch_add(&tax->ws_calls, 1, __ATOMIC_RELAXED);
     const bool same_table = tax->ws_kind_key_ptr == seg_off && tax->ws_kind_key_n == n_queries;
     if (!tax->ws_kind_host || (call & 63u) == 0 || !same_table) {
-        if (tax->ws_kind_host) __atomic_store_n(tax->ws_kind_host, 0u, __ATOMIC_RELAXED);   // (until the device reports this table's kind)
+        if (tax->ws_kind_host) {   // (until the device reports this table's kind and queue length)
+            __atomic_store_n(tax->ws_kind_host, 0u, __ATOMIC_RELAXED);
+            __atomic_store_n(tax->ws_kind_host + 1, 0xFFFFFFFFu, __ATOMIC_RELAXED);
+        }
         tax->ws_kind_key_ptr = seg_off; tax->ws_kind_key_n = n_queries;
-        return 0u;
+        return forced_kind;
     }
-    return __atomic_load_n(tax->ws_kind_host, __ATOMIC_RELAXED);
+    const uint32_t kind = forced_kind ? forced_kind : __atomic_load_n(tax->ws_kind_host, __ATOMIC_RELAXED);
+    // the queue length the table's last run reported: next to nothing -> no launch of the worklist kernel (BLU_NO_TAIL=1: always launch it)
+    const uint32_t last_len = __atomic_load_n(tax->ws_kind_host + 1, __ATOMIC_RELAXED);
+    static const bool never = getenv("BLU_NO_TAIL") != nullptr;
+    return kind | ((last_len <= 32u && !never) ? 4u : 0u);
 }
 
 extern "C" {
@@ -78,7 +86,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
             if (hipMemset(tax->ws_count, 0, 256) != hipSuccess) { set_error("hipMemset(workspace) failed"); return BLU_ERR_HIP; }
             // (without the pinned word every call classifies its table on the device: slower by two kernel boundaries, not wrong)
             if (hipHostMalloc((void**)&tax->ws_kind_host, 64, hipHostMallocDefault) == hipSuccess) {
-                *tax->ws_kind_host = 0;
+                tax->ws_kind_host[0] = 0; tax->ws_kind_host[1] = 0xFFFFFFFFu;
                 if (hipHostGetDevicePointer((void**)&tax->ws_kind_dev, tax->ws_kind_host, 0) != hipSuccess) tax->ws_kind_dev = nullptr;
             } else { (void)hipGetLastError(); tax->ws_kind_host = nullptr; }
         }

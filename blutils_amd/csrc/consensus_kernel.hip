@@ -276,6 +276,10 @@ __device__ __forceinline__ uint32_t shared_levels(const TaxDev& t, uint32_t lo, 
 // ===============================================================================
 // Kernel A
 // ===============================================================================
+struct HitsDev;
+template <int STRAT, int LAYOUT>
+__device__ __forceinline__ void consensus_of_long_query(const HitsDev& h, const TaxDev& t, blu_result* __restrict__ out, const uint64_t q,
+                                                        uint32_t* const slot, const int lane);   // (defined with kernel B)
 template <bool PID32> struct PidKey { typedef double type; };
 template <> struct PidKey<true> { typedef uint32_t type; };
 template <bool PID32>
@@ -418,7 +422,12 @@ static_assert(RING_CHUNKS <= 16, "wait_vmcnt covers 0..15 younger chunks");
 template <int STRAT, int LAYOUT, bool RING>
 __global__ __launch_bounds__((RING || LAYOUT == 0 || LAYOUT == 3) ? BLOCK_A : BLOCK_N, (RING || LAYOUT == 0 || LAYOUT == 3) ? BLU_WAVES_PER_SIMD : BLU_N_WAVES_PER_SIMD)
 void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out, uint32_t* __restrict__ worklist, uint32_t* __restrict__ work_count,
-                                 uint32_t forced) {
+                                 uint32_t mode, uint32_t* __restrict__ host_len) {
+    // mode bit 0 ("forced"): the host launched this kind alone; bit 1 ("no worklist kernel"): no launch of kernel B follows this
+    // one — the last run on this table left (next to) nothing in the queue — so whatever is queued after all is drained by the
+    // last block of this kernel to finish (slow if it is much, never wrong); host_len: pinned host word the queue length goes to
+    const uint32_t forced = mode & 1u;
+    const bool no_long = (mode & 2u) != 0u;
     // PACKED: 16-byte side records (milli-percent), WIDE: 24-byte side records (f64 perc_identity in words 4, 5)
     constexpr bool PID32 = LAYOUT == 1 || LAYOUT == 2, PACKED = LAYOUT == 2, WIDE = LAYOUT == 3;
     constexpr uint32_t BLOCK_T = (RING || !PID32) ? BLOCK_A : BLOCK_N, WAVES_T = BLOCK_T / WAVE;   // (the f64 layouts do not fit 128 VGPRs)
@@ -1537,11 +1546,12 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             uint4 ck[4] = {};
             uint32_t shape_req = 0xFFFFFFFFu;
             if constexpr (PACKED) {
-                const uint32_t guess = r_hint ? umin(r_hint - 1u, t.n_shapes - 1u) : 0u;
-                const uint4* kg = reinterpret_cast<const uint4*>(t.kthr + (uint64_t)guess * t.cstride);
+                if (r_hint) {   // (no hint — more shapes than the hint has room for, a record put together by hand, a dense step: below)
+                    shape_req = umin(r_hint - 1u, t.n_shapes - 1u);
+                    const uint4* kg = reinterpret_cast<const uint4*>(t.kthr + (uint64_t)shape_req * t.cstride);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) ck[k] = kg[k];
-                shape_req = r_hint ? guess : 0xFFFFFFFFu;
+                    for (int k = 0; k < 4; ++k) ck[k] = kg[k];
+                }
             }
             // Levels shared by the whole group (find_multi_taxa_consensus.rs:137-180): every row agrees with the reference row on
             // exactly the levels all rows of the span [lo, hi] share, and the scan never looks past the shortest lineage.
@@ -1551,7 +1561,11 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             // those lookups travel together with the reference row instead of after it.
             const bool spread = !single && g_lo < g_hi && !BLU_X_SKIP_RUNLEN;
             const uint32_t dl = r_row - g_lo, dh = g_hi - r_row;     // lo <= reference row <= hi
+#ifdef BLU_X_NO_WIDE
+            const bool wide = false;   // (timing only: wrong records for wide groups)
+#else
             const bool wide = spread && (dl > BLU_ROW_RUN_MAX || dh > BLU_ROW_RUN_MAX);   // saturated run lengths: not decidable from the row
+#endif
             uint32_t d_tab = 0;
             if (wide) d_tab = shared_levels(t, g_lo, g_hi);
             STAMP_DRAIN
@@ -1764,16 +1778,35 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     }
 #endif
     // The last block to finish publishes the queue length for the worklist kernel and zeroes the two counters: a run
-    // leaves them as it found them — no memset between runs, and a captured graph of the two kernels can be replayed.
+    // leaves them as it found them — no memset between runs, and a captured graph of the kernels can be replayed.  The length
+    // also goes to a pinned host word: the next call on this table launches no worklist kernel when it was (next to) nothing
+    // — a kernel boundary costs more than a C4 slice can afford — and if the queue is not empty after all, this block, the
+    // last one running, works it off itself (every other block has finished and published its entries).
+    __shared__ uint32_t s_drain;
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
         const uint32_t ticket = atomicAdd(work_count + 1, 1u);
+        uint32_t drain = 0;
         if (ticket == gridDim.x - 1) {
             const uint32_t n = __hip_atomic_load(work_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(work_count + 2, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (host_len) __hip_atomic_store(host_len, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            drain = no_long ? n : 0u;
+            __hip_atomic_store(work_count + 2, no_long ? 0u : n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(work_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(work_count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_drain = drain;
+    }
+    if (no_long) {
+        __syncthreads();
+        const uint32_t n = s_drain;
+        if (n) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the entries other blocks queued
+            uint32_t* const slot = reinterpret_cast<uint32_t*>(&L.rec[0]);
+            static_assert(sizeof(L.rec) >= SLOT_CAP * sizeof(uint32_t), "the list area holds the slots of a worklist query");
+            for (uint32_t wi = (uint32_t)wib; wi < n; wi += WAVES_T)
+                consensus_of_long_query<STRAT, LAYOUT>(h, t, out, (uint64_t)__hip_atomic_load(worklist + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), slot, lane);
         }
     }
 }
@@ -1812,271 +1845,281 @@ __device__ __forceinline__ int select_reference(bool valid, uint32_t len, uint32
     return first_lane(cand);
 }
 
+// One worklist query, handled by one whole wave (any segment length).  `slot`: SLOT_CAP words of LDS of this wave.
+// Called by the worklist kernel (one wave per query, 32 waves per CU) and by the tail of the stream kernel, whose waves drain
+// a short queue themselves instead of leaving it to a second launch.
+template <int STRAT, int LAYOUT>
+__device__ __forceinline__ void consensus_of_long_query(const HitsDev& h, const TaxDev& t, blu_result* __restrict__ out, const uint64_t q,
+                                                        uint32_t* const slot, const int lane) {
+    constexpr bool PID32 = LAYOUT == 1 || LAYOUT == 2, PACKED = LAYOUT == 2, WIDE = LAYOUT == 3;
+    uint64_t start = h.seg_off[q], end = h.seg_off[q + 1];
+    if (end > h.n_hits) end = h.n_hits;
+    if (start > end) start = end;
+    start = uniform64(start);
+    const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)(end - start));   // n_hits < 2^32
+    const int32_t* c_bs = h.bitscore + start;
+    const uint32_t* c_tax = (PACKED || WIDE) ? nullptr : h.tax_row + start;
+    const double* c_pid = (PID32 || WIDE) ? nullptr : h.pident + start;
+    const uint32_t* c_pm = (PID32 && !PACKED) ? h.pident_milli + start : nullptr;
+    const int32_t* c_aln = (PACKED || WIDE) ? nullptr : h.align_len + start;
+    const uint32_t* c_acc = (PACKED || WIDE) ? nullptr : h.acc_rank + start;
+    const u32x4* c_pk = PACKED ? reinterpret_cast<const u32x4*>(h.packed) + start : nullptr;   // 16-byte records
+    const u32x2* c_pw = WIDE ? reinterpret_cast<const u32x2*>(h.packed64) + 3 * start : nullptr;   // 24-byte records
+    // group size, errors in file order, lane-local best key / shortest lineage / max pident (filled by either path below)
+    uint32_t k = 0, err_status = 0, err_row = 0;
+    uint32_t have = 0, b_len = 0, b_acc = 0, b_pos = 0, b_row = 0, l_minlen = 0xFFFFFFFFu;
+    uint32_t l_lo = 0xFFFFFFFFu, l_hi = 0;   // span of this lane's top rows in the sorted lineage order
+    uint32_t l_nan = 0xFFFFFFFFu;             // this lane's first top row with a NaN perc_identity (f64 layout only)
+    int b_aln = 0;
+    double b_pid = 0.0, l_maxpid = 0.0;
+    // The rows of the top group are collected in the slots (in no particular order) and their side records gathered one
+    // row per lane: one memory round trip per 64 top rows wherever they sit in the segment.  A lane's running best
+    // settles ties on all four keys by the row index (Relaxed: the later row, Cautious: the earlier one) — the rule
+    // the stable sort + .last() / .first() of find_multi_taxa_consensus.rs:39-68 amounts to.
+    uint32_t l_err_row = 0xFFFFFFFFu, l_err_kind = 0;   // this lane's first failing top row (parse_taxonomy Err, find_single_query_consensus.rs:58-60)
+    uint32_t kk = 0;                                     // slots in use (wave-uniform)
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t b = 0; b < kk; b += WAVE) {
+            const bool top = b + (uint32_t)lane < kk;
+            const uint32_t i = top ? slot[b + (uint32_t)lane] : 0u;
+            uint32_t tax, acc;
+            int aln;
+            double pid;
+            if (PACKED) { const u32x4 rec = c_pk[i]; tax = rec.x; pid = milli_to_f64(rec.y & PM_MASK); aln = (int)rec.z; acc = rec.w; }   // (bits 17.. of word 1: the shape hint)
+            else if (WIDE) {
+                const u32x2 a = c_pw[3ull * i], b = c_pw[3ull * i + 1], c = c_pw[3ull * i + 2];
+                tax = a.x; aln = (int)b.x; acc = b.y; pid = __hiloint2double((int)c.y, (int)c.x);
+            }
+            else { tax = c_tax[i]; pid = PID32 ? milli_to_f64(c_pm[i]) : c_pid[i]; aln = c_aln[i]; acc = c_acc[i]; }
+            const uint32_t pos = tax & ROW_MASK;
+            const bool unmatched = top && pos >= t.n_tax;
+            const uint32_t len = umin(tax >> BLU_ROW_BITS, t.max_depth);
+            const bool bad = top && !unmatched && len == 0;
+            const bool first_err = (unmatched | bad) && i < l_err_row;
+            l_err_kind = first_err ? (bad ? (uint32_t)BLU_ST_ERR_BAD_LINEAGE : (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID) : l_err_kind;
+            l_err_row = first_err ? i : l_err_row;
+            // Relaxed keeps the greatest key (ties on all four: the later row), Cautious the smallest (the earlier row): one strict
+            // comparison chain in the strategy's own direction (a NaN compares false either way; NaN groups are refused below)
+            const bool ahead = STRAT == BLU_RELAXED
+                ? (len > b_len) | ((len == b_len) & ((pid > b_pid) | ((pid == b_pid) & ((aln > b_aln) | ((aln == b_aln) & (acc > b_acc))))))
+                : (len < b_len) | ((len == b_len) & ((pid < b_pid) | ((pid == b_pid) & ((aln < b_aln) | ((aln == b_aln) & (acc < b_acc))))));
+            const bool eq = (len == b_len) & (pid == b_pid) & (aln == b_aln) & (acc == b_acc);
+            const bool better = ahead | (eq & (STRAT == BLU_RELAXED ? i > b_pos : i < b_pos));
+            const bool take = top & ((have == 0) | better);
+            have = top ? 1u : have;
+            b_len = take ? len : b_len;
+            b_pid = take ? pid : b_pid;
+            b_aln = take ? aln : b_aln;
+            b_acc = take ? acc : b_acc;
+            b_pos = take ? i : b_pos;
+            b_row = take ? pos : b_row;
+            l_minlen = top ? umin(l_minlen, len) : l_minlen;
+            l_lo = top ? umin(l_lo, pos) : l_lo;
+            l_hi = (top && pos > l_hi) ? pos : l_hi;
+            l_maxpid = (top && pid > l_maxpid) ? pid : l_maxpid;
+            if (!PID32) l_nan = (top && pid != pid) ? umin(l_nan, i) : l_nan;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        kk = 0;
+    };
+    auto collect = [&](const bool top, const uint32_t i) {   // one 64-row group of the segment: its top rows into the slots
+        const uint64_t mask = __ballot(top);
+        if (!mask) return;
+        if (top) slot[kk + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = i;
+        const uint32_t add = (uint32_t)__builtin_popcountll(mask);
+        kk += add;
+        k += add;
+        if (kk > SLOT_CAP - WAVE) flush();
+    };
+    if (n <= KEEP_ROWS) {
+        // ---- a segment of up to 1024 rows: one round trip for its bit-scores (four 16-byte loads per lane), the top score
+        // and the top rows come out of the registers
+        const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)c_bs, 0, n * 4u, 0x00020000);
+        u32x4 w[KEEP_ROWS / 256];
+#pragma unroll
+        for (uint32_t u = 0; u < KEEP_ROWS / 256; ++u) {
+            w[u] = u32x4{0u, 0u, 0u, 0u};
+            if (u * 256u < n) w[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (u * 256u + (uint32_t)lane * 4u) * 4u, 0, 0);
+        }
+        int m = INT_MIN;
+#pragma unroll
+        for (uint32_t u = 0; u < KEEP_ROWS / 256; ++u) {
+            const uint32_t i0 = u * 256u + (uint32_t)lane * 4u;
+            m = imax(m, i0 < n ? (int)w[u].x : INT_MIN);
+            m = imax(m, i0 + 1 < n ? (int)w[u].y : INT_MIN);
+            m = imax(m, i0 + 2 < n ? (int)w[u].z : INT_MIN);
+            m = imax(m, i0 + 3 < n ? (int)w[u].w : INT_MIN);
+        }
+        const int M = wave_max_i32(m);
+#pragma unroll
+        for (uint32_t u = 0; u < KEEP_ROWS / 256; ++u) {
+            if (u * 256u >= n) continue;      // (wave-uniform)
+            const uint32_t vv[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+                const uint32_t i = u * 256u + (uint32_t)lane * 4u + c;
+                collect(i < n && (int)vv[c] == M, i);
+            }
+        }
+    } else {
+    // pass 1: top score
+    // 16-byte loads, four per lane in flight (1024 rows per iteration); rows past the segment read as 0 from the
+    // range-checked descriptor and are masked by index
+    int m = INT_MIN;
+    uint32_t c_first = 0, c_last = 0;   // first / last 1024-row chunk (its first row) in which this lane saw its running maximum
+    u32x4 v[4] = {};   // (a segment of up to 1024 rows stays in these registers for pass 2)
+    for (uint64_t sb = 0; sb < n; sb += LONG_SPAN) {   // descriptors cover LONG_SPAN rows: byte offsets stay below 2^32
+        const uint32_t ns = (n - sb) < LONG_SPAN ? (uint32_t)(n - sb) : LONG_SPAN;
+        const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(c_bs + sb), 0, ns * 4u, 0x00020000);
+        for (uint32_t base = 0; base < ns; base += 1024) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
+            int cl = INT_MIN;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i0 = base + u * 256 + (uint32_t)lane * 4u;
+                cl = imax(cl, i0 < ns ? (int)v[u].x : INT_MIN);
+                cl = imax(cl, i0 + 1 < ns ? (int)v[u].y : INT_MIN);
+                cl = imax(cl, i0 + 2 < ns ? (int)v[u].z : INT_MIN);
+                cl = imax(cl, i0 + 3 < ns ? (int)v[u].w : INT_MIN);
+            }
+            const uint32_t cb = (uint32_t)sb + base;
+            c_first = cl > m ? cb : c_first;
+            c_last = cl >= m ? cb : c_last;
+            m = imax(m, cl);
+        }
+    }
+    const int M = wave_max_i32(m);
+    // pass 2 only walks the chunks that can hold a top row: BLAST writes a query's hits best first, so this is
+    // usually the first chunk alone (lanes that never reached M do not count; chunk starts are multiples of 1024)
+    const uint32_t w_first = wave_min_u32(m == M ? c_first : 0xFFFFFFFFu);
+    const uint32_t w_last = wave_max_u32(m == M ? c_last : 0u);
+    // pass 2: group size, errors in file order, lane-local best key / shortest lineage / max pident
+    for (uint64_t cb = w_first; cb <= w_last && cb < n; cb += 1024) {
+    {
+    const uint64_t sb = cb / LONG_SPAN * LONG_SPAN;
+    const uint32_t base = (uint32_t)(cb - sb);
+    const uint32_t ns = (n - sb) < LONG_SPAN ? (uint32_t)(n - sb) : LONG_SPAN;
+    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(c_bs + sb), 0, ns * 4u, 0x00020000);
+      // 1024 rows per round trip, as in pass 1 (four 16-byte loads per lane in flight); top rows are sparse, so most of
+      // the sixteen 64-row groups end at the ballot.  Lane l holds rows base + 256 u + 4 l + c: a lane sees its rows
+      // in file order, which is all the running selects below need (ties across lanes are settled by row index).
+      if (n > 1024u) {   // (wave-uniform) a shorter segment is still in the registers pass 1 filled: one round trip less
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
+      }
+      for (int u = 0; u < 4; ++u) {
+        if (base + (uint32_t)u * 256 >= ns) break;
+        const u32x4 cur = u == 0 ? v[0] : (u == 1 ? v[1] : (u == 2 ? v[2] : v[3]));
+        const uint32_t vv[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t iloc = base + (uint32_t)u * 256 + (uint32_t)lane * 4u + (uint32_t)c;
+            collect(iloc < ns && (int)vv[c] == M, (uint32_t)sb + iloc);   // (row index inside the segment)
+        }
+      }
+    }
+    }
+    }   // (segments over KEEP_ROWS rows)
+    if (kk) flush();
+    {
+        const uint32_t first_err = wave_min_u32(l_err_row);
+        if (first_err != 0xFFFFFFFFu) {
+            err_row = first_err;
+            err_status = (uint32_t)rl((int)l_err_kind, first_lane(__ballot(l_err_row == first_err)));
+        }
+    }
+    if (err_status) {
+        if (lane == 0) store_status(out, q, err_status, (uint32_t)start + err_row);
+        return;
+    }
+    // NaN pident anywhere in the top group (after the parse errors, which win): its first row in file order, gathered
+    // by pass 2 (the milli-percent layouts have no NaN)
+    if (!PID32) {
+        const uint32_t nan_row = wave_min_u32(l_nan);
+        if (nan_row != 0xFFFFFFFFu) {
+            if (lane == 0) store_status(out, q, BLU_ST_ERR_BAD_PIDENT, (uint32_t)start + nan_row);
+            return;
+        }
+    }
+    if (n == 0) {
+        if (lane == 0) store_status(out, q, BLU_ST_NO_HITS, 0xFFFFFFFFu);
+        return;
+    }
+    int rlane;
+    if (k == 1) rlane = first_lane(__ballot(have != 0));
+    else {
+        const uint32_t len_ext = STRAT == BLU_RELAXED ? wave_max_u32(have ? b_len : 0u) : wave_min_u32(have ? b_len : 0xFFFFFFFFu);
+        rlane = select_reference<STRAT>(have != 0, b_len, len_ext, b_pid, b_aln, b_acc, b_pos);
+    }
+    const uint32_t row_ref = (uint32_t)rl((int)b_row, rlane);
+    const uint32_t len_ref = (uint32_t)rl((int)b_len, rlane);
+
+    const uint32_t pos_ref = (uint32_t)rl((int)b_pos, rlane);
+    const double pid_ref = rl_f64(b_pid, rlane);
+    const bool in_l = (uint32_t)lane < len_ref;
+    const uint32_t lvl = in_l ? (uint32_t)lane : 0u;
+    // the span of the group is known here: its range-minimum lookup travels together with the reference row
+    const uint32_t minlen = wave_min_u32(l_minlen);
+    const uint32_t lo = wave_min_u32(l_lo), hi = wave_max_u32(l_hi);
+    const uint32_t hdr_ref = t.lin[(uint64_t)row_ref * t.stride];
+    const uint32_t ref_node = t.lin[(uint64_t)row_ref * t.stride + BLU_ROW_NODE_BASE + lvl];
+    uint32_t d = minlen;
+    if (k != 1 && lo < hi) d = umin(minlen, shared_levels(t, lo, hi));   // levels shared by the whole top group (:137-180)
+    const uint32_t shape_ref = hdr_ref >> 8;
+    const uint32_t packed = t.codes[(uint64_t)shape_ref * t.cstride + lvl];
+    const double cut = t.cutvals[packed & ((1u << BLU_PACK_CUT_BITS) - 1u)];
+    const uint32_t codes = packed_rank(packed) | (packed_mar(packed) << 16);
+    const uint32_t ref_row = (uint32_t)start + pos_ref;
+    if (k == 1) {   // find_single_query_consensus.rs:74-150
+        const uint64_t A = __ballot(in_l && pid_ref >= cut);
+        if (A == 0) { if (lane == 0) store_status(out, q, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, ref_row); return; }
+        const uint32_t last = (uint32_t)last_lane(A);
+        const uint32_t ident_node = (uint32_t)rl((int)ref_node, (int)last);
+        const uint32_t reached = (uint32_t)rl((int)codes, (int)last) & 0xFFFF;
+        if (lane == 0) store_result(out, q, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, reached, BLU_NONE_U16, ident_node, ref_row, A, pid_ref);
+        return;
+    }
+    const bool agree = d >= minlen;
+    if (!agree && d == 0) { if (lane == 0) store_status(out, q, BLU_ST_ERR_ROOT_DISAGREE, ref_row); return; }
+    const uint32_t b = agree ? minlen - 1 : d - 1;
+    double max_pid = 0.0;
+    if (!agree) max_pid = wave_max_f64(l_maxpid);   // fold(0.0, |acc, i| if i > acc {i} else {acc})
+    const double ident = agree ? pid_ref : max_pid;
+    const uint64_t F = __ballot(in_l && ident >= cut);
+    const uint64_t NG = __ballot(in_l && !(ident > cut));
+    uint64_t A = F;
+    if (!agree) {
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(F >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F, 0u));
+        A = __ballot(((F >> lane) & 1) && before <= b);
+    }
+    const uint32_t last = A ? (uint32_t)last_lane(A) : b;
+    const uint32_t ident_node = (uint32_t)rl((int)ref_node, (int)last);
+    const uint32_t reached = (uint32_t)rl((int)codes, (int)last) & 0xFFFF;
+    uint32_t mar_level = BLU_NONE_U8, mar_code = BLU_NONE_U16, flags = agree ? BLU_FLAG_AGREE : 0u;
+    if (NG) {
+        mar_level = (uint32_t)first_lane(NG);
+        mar_code = ((uint32_t)rl((int)codes, (int)mar_level)) >> 16;
+        if (mar_code != ((uint32_t)rl((int)codes, (int)b) & 0xFFFF)) flags |= BLU_FLAG_MUTATED;
+    }
+    if (lane == 0) store_result(out, q, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, reached, mar_code, ident_node, ref_row, A, ident);
+}
+
 template <int STRAT, int LAYOUT>
 __global__ __launch_bounds__(BLOCK_B, BLU_B_WAVES_PER_SIMD) void blu_consensus_long_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out,
                                                                  const uint32_t* __restrict__ worklist,
                                                                  const uint32_t* __restrict__ work_count) {
-    constexpr bool PID32 = LAYOUT == 1 || LAYOUT == 2, PACKED = LAYOUT == 2, WIDE = LAYOUT == 3;
     __shared__ uint32_t s_slot[BLOCK_B / WAVE][SLOT_CAP];   // rows of the top group found so far (segments kept in registers)
-    const int lane = lane_id();
     uint32_t* const slot = s_slot[__builtin_amdgcn_readfirstlane(threadIdx.x / WAVE)];
-    const uint32_t n_work = work_count[2];   // queue length published by the stream kernel's last block
+    const uint32_t n_work = work_count[2];   // queue length published by the stream kernel's last block (0 when its waves drained the queue themselves)
     const uint32_t wave = blockIdx.x * (blockDim.x / WAVE) + __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     const uint32_t n_waves = gridDim.x * (blockDim.x / WAVE);
-    for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
-        const uint64_t q = worklist[wi];
-        uint64_t start = h.seg_off[q], end = h.seg_off[q + 1];
-        if (end > h.n_hits) end = h.n_hits;
-        if (start > end) start = end;
-        start = uniform64(start);
-        const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)(end - start));   // n_hits < 2^32
-        const int32_t* c_bs = h.bitscore + start;
-        const uint32_t* c_tax = (PACKED || WIDE) ? nullptr : h.tax_row + start;
-        const double* c_pid = (PID32 || WIDE) ? nullptr : h.pident + start;
-        const uint32_t* c_pm = (PID32 && !PACKED) ? h.pident_milli + start : nullptr;
-        const int32_t* c_aln = (PACKED || WIDE) ? nullptr : h.align_len + start;
-        const uint32_t* c_acc = (PACKED || WIDE) ? nullptr : h.acc_rank + start;
-        const u32x4* c_pk = PACKED ? reinterpret_cast<const u32x4*>(h.packed) + start : nullptr;   // 16-byte records
-        const u32x2* c_pw = WIDE ? reinterpret_cast<const u32x2*>(h.packed64) + 3 * start : nullptr;   // 24-byte records
-        // group size, errors in file order, lane-local best key / shortest lineage / max pident (filled by either path below)
-        uint32_t k = 0, err_status = 0, err_row = 0;
-        uint32_t have = 0, b_len = 0, b_acc = 0, b_pos = 0, b_row = 0, l_minlen = 0xFFFFFFFFu;
-        uint32_t l_lo = 0xFFFFFFFFu, l_hi = 0;   // span of this lane's top rows in the sorted lineage order
-        uint32_t l_nan = 0xFFFFFFFFu;             // this lane's first top row with a NaN perc_identity (f64 layout only)
-        int b_aln = 0;
-        double b_pid = 0.0, l_maxpid = 0.0;
-        // The rows of the top group are collected in the slots (in no particular order) and their side records gathered one
-        // row per lane: one memory round trip per 64 top rows wherever they sit in the segment.  A lane's running best
-        // settles ties on all four keys by the row index (Relaxed: the later row, Cautious: the earlier one) — the rule
-        // the stable sort + .last() / .first() of find_multi_taxa_consensus.rs:39-68 amounts to.
-        uint32_t l_err_row = 0xFFFFFFFFu, l_err_kind = 0;   // this lane's first failing top row (parse_taxonomy Err, find_single_query_consensus.rs:58-60)
-        uint32_t kk = 0;                                     // slots in use (wave-uniform)
-        auto flush = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            for (uint32_t b = 0; b < kk; b += WAVE) {
-                const bool top = b + (uint32_t)lane < kk;
-                const uint32_t i = top ? slot[b + (uint32_t)lane] : 0u;
-                uint32_t tax, acc;
-                int aln;
-                double pid;
-                if (PACKED) { const u32x4 rec = c_pk[i]; tax = rec.x; pid = milli_to_f64(rec.y & PM_MASK); aln = (int)rec.z; acc = rec.w; }   // (bits 17.. of word 1: the shape hint)
-                else if (WIDE) {
-                    const u32x2 a = c_pw[3ull * i], b = c_pw[3ull * i + 1], c = c_pw[3ull * i + 2];
-                    tax = a.x; aln = (int)b.x; acc = b.y; pid = __hiloint2double((int)c.y, (int)c.x);
-                }
-                else { tax = c_tax[i]; pid = PID32 ? milli_to_f64(c_pm[i]) : c_pid[i]; aln = c_aln[i]; acc = c_acc[i]; }
-                const uint32_t pos = tax & ROW_MASK;
-                const bool unmatched = top && pos >= t.n_tax;
-                const uint32_t len = umin(tax >> BLU_ROW_BITS, t.max_depth);
-                const bool bad = top && !unmatched && len == 0;
-                const bool first_err = (unmatched | bad) && i < l_err_row;
-                l_err_kind = first_err ? (bad ? (uint32_t)BLU_ST_ERR_BAD_LINEAGE : (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID) : l_err_kind;
-                l_err_row = first_err ? i : l_err_row;
-                const bool gt = (len > b_len) | ((len == b_len) & ((pid > b_pid) | ((pid == b_pid) & ((aln > b_aln) | ((aln == b_aln) & (acc > b_acc))))));
-                const bool eq = (len == b_len) & (pid == b_pid) & (aln == b_aln) & (acc == b_acc);
-                const bool better = STRAT == BLU_RELAXED ? (gt | (eq & (i > b_pos))) : ((!gt & !eq) | (eq & (i < b_pos)));
-                const bool take = top & ((have == 0) | better);
-                have = top ? 1u : have;
-                b_len = take ? len : b_len;
-                b_pid = take ? pid : b_pid;
-                b_aln = take ? aln : b_aln;
-                b_acc = take ? acc : b_acc;
-                b_pos = take ? i : b_pos;
-                b_row = take ? pos : b_row;
-                l_minlen = top ? umin(l_minlen, len) : l_minlen;
-                l_lo = top ? umin(l_lo, pos) : l_lo;
-                l_hi = (top && pos > l_hi) ? pos : l_hi;
-                l_maxpid = (top && pid > l_maxpid) ? pid : l_maxpid;
-                if (!PID32) l_nan = (top && pid != pid) ? umin(l_nan, i) : l_nan;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            kk = 0;
-        };
-        auto collect = [&](const bool top, const uint32_t i) {   // one 64-row group of the segment: its top rows into the slots
-            const uint64_t mask = __ballot(top);
-            if (!mask) return;
-            if (top) slot[kk + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = i;
-            const uint32_t add = (uint32_t)__builtin_popcountll(mask);
-            kk += add;
-            k += add;
-            if (kk > SLOT_CAP - WAVE) flush();
-        };
-        if (n <= KEEP_ROWS) {
-            // ---- a segment of up to 1024 rows: one round trip for its bit-scores (four 16-byte loads per lane), the top score
-            // and the top rows come out of the registers
-            const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)c_bs, 0, n * 4u, 0x00020000);
-            u32x4 w[KEEP_ROWS / 256];
-#pragma unroll
-            for (uint32_t u = 0; u < KEEP_ROWS / 256; ++u) {
-                w[u] = u32x4{0u, 0u, 0u, 0u};
-                if (u * 256u < n) w[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (u * 256u + (uint32_t)lane * 4u) * 4u, 0, 0);
-            }
-            int m = INT_MIN;
-#pragma unroll
-            for (uint32_t u = 0; u < KEEP_ROWS / 256; ++u) {
-                const uint32_t i0 = u * 256u + (uint32_t)lane * 4u;
-                m = imax(m, i0 < n ? (int)w[u].x : INT_MIN);
-                m = imax(m, i0 + 1 < n ? (int)w[u].y : INT_MIN);
-                m = imax(m, i0 + 2 < n ? (int)w[u].z : INT_MIN);
-                m = imax(m, i0 + 3 < n ? (int)w[u].w : INT_MIN);
-            }
-            const int M = wave_max_i32(m);
-#pragma unroll
-            for (uint32_t u = 0; u < KEEP_ROWS / 256; ++u) {
-                if (u * 256u >= n) continue;      // (wave-uniform)
-                const uint32_t vv[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
-#pragma unroll
-                for (uint32_t c = 0; c < 4; ++c) {
-                    const uint32_t i = u * 256u + (uint32_t)lane * 4u + c;
-                    collect(i < n && (int)vv[c] == M, i);
-                }
-            }
-        } else {
-        // pass 1: top score
-        // 16-byte loads, four per lane in flight (1024 rows per iteration); rows past the segment read as 0 from the
-        // range-checked descriptor and are masked by index
-        int m = INT_MIN;
-        uint32_t c_first = 0, c_last = 0;   // first / last 1024-row chunk (its first row) in which this lane saw its running maximum
-        u32x4 v[4] = {};   // (a segment of up to 1024 rows stays in these registers for pass 2)
-        for (uint64_t sb = 0; sb < n; sb += LONG_SPAN) {   // descriptors cover LONG_SPAN rows: byte offsets stay below 2^32
-            const uint32_t ns = (n - sb) < LONG_SPAN ? (uint32_t)(n - sb) : LONG_SPAN;
-            const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(c_bs + sb), 0, ns * 4u, 0x00020000);
-            for (uint32_t base = 0; base < ns; base += 1024) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
-                int cl = INT_MIN;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t i0 = base + u * 256 + (uint32_t)lane * 4u;
-                    cl = imax(cl, i0 < ns ? (int)v[u].x : INT_MIN);
-                    cl = imax(cl, i0 + 1 < ns ? (int)v[u].y : INT_MIN);
-                    cl = imax(cl, i0 + 2 < ns ? (int)v[u].z : INT_MIN);
-                    cl = imax(cl, i0 + 3 < ns ? (int)v[u].w : INT_MIN);
-                }
-                const uint32_t cb = (uint32_t)sb + base;
-                c_first = cl > m ? cb : c_first;
-                c_last = cl >= m ? cb : c_last;
-                m = imax(m, cl);
-            }
-        }
-        const int M = wave_max_i32(m);
-        // pass 2 only walks the chunks that can hold a top row: BLAST writes a query's hits best first, so this is
-        // usually the first chunk alone (lanes that never reached M do not count; chunk starts are multiples of 1024)
-        const uint32_t w_first = wave_min_u32(m == M ? c_first : 0xFFFFFFFFu);
-        const uint32_t w_last = wave_max_u32(m == M ? c_last : 0u);
-        // pass 2: group size, errors in file order, lane-local best key / shortest lineage / max pident
-        for (uint64_t cb = w_first; cb <= w_last && cb < n; cb += 1024) {
-        {
-        const uint64_t sb = cb / LONG_SPAN * LONG_SPAN;
-        const uint32_t base = (uint32_t)(cb - sb);
-        const uint32_t ns = (n - sb) < LONG_SPAN ? (uint32_t)(n - sb) : LONG_SPAN;
-        const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(c_bs + sb), 0, ns * 4u, 0x00020000);
-          // 1024 rows per round trip, as in pass 1 (four 16-byte loads per lane in flight); top rows are sparse, so most of
-          // the sixteen 64-row groups end at the ballot.  Lane l holds rows base + 256 u + 4 l + c: a lane sees its rows
-          // in file order, which is all the running selects below need (ties across lanes are settled by row index).
-          if (n > 1024u) {   // (wave-uniform) a shorter segment is still in the registers pass 1 filled: one round trip less
-#pragma unroll
-              for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (base + u * 256 + (uint32_t)lane * 4u) * 4u, 0, 0);
-          }
-          for (int u = 0; u < 4; ++u) {
-            if (base + (uint32_t)u * 256 >= ns) break;
-            const u32x4 cur = u == 0 ? v[0] : (u == 1 ? v[1] : (u == 2 ? v[2] : v[3]));
-            const uint32_t vv[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t iloc = base + (uint32_t)u * 256 + (uint32_t)lane * 4u + (uint32_t)c;
-                collect(iloc < ns && (int)vv[c] == M, (uint32_t)sb + iloc);   // (row index inside the segment)
-            }
-          }
-        }
-        }
-        }   // (segments over KEEP_ROWS rows)
-        if (kk) flush();
-        {
-            const uint32_t first_err = wave_min_u32(l_err_row);
-            if (first_err != 0xFFFFFFFFu) {
-                err_row = first_err;
-                err_status = (uint32_t)rl((int)l_err_kind, first_lane(__ballot(l_err_row == first_err)));
-            }
-        }
-        if (err_status) {
-            if (lane == 0) store_status(out, q, err_status, (uint32_t)start + err_row);
-            continue;
-        }
-        // NaN pident anywhere in the top group (after the parse errors, which win): its first row in file order, gathered
-        // by pass 2 (the milli-percent layouts have no NaN)
-        if (!PID32) {
-            const uint32_t nan_row = wave_min_u32(l_nan);
-            if (nan_row != 0xFFFFFFFFu) {
-                if (lane == 0) store_status(out, q, BLU_ST_ERR_BAD_PIDENT, (uint32_t)start + nan_row);
-                continue;
-            }
-        }
-        if (n == 0) {
-            if (lane == 0) store_status(out, q, BLU_ST_NO_HITS, 0xFFFFFFFFu);
-            continue;
-        }
-        int rlane;
-        if (k == 1) rlane = first_lane(__ballot(have != 0));
-        else {
-            const uint32_t len_ext = STRAT == BLU_RELAXED ? wave_max_u32(have ? b_len : 0u) : wave_min_u32(have ? b_len : 0xFFFFFFFFu);
-            rlane = select_reference<STRAT>(have != 0, b_len, len_ext, b_pid, b_aln, b_acc, b_pos);
-        }
-        const uint32_t row_ref = (uint32_t)rl((int)b_row, rlane);
-        const uint32_t len_ref = (uint32_t)rl((int)b_len, rlane);
-
-        const uint32_t pos_ref = (uint32_t)rl((int)b_pos, rlane);
-        const double pid_ref = rl_f64(b_pid, rlane);
-        const bool in_l = (uint32_t)lane < len_ref;
-        const uint32_t lvl = in_l ? (uint32_t)lane : 0u;
-        // the span of the group is known here: its range-minimum lookup travels together with the reference row
-        const uint32_t minlen = wave_min_u32(l_minlen);
-        const uint32_t lo = wave_min_u32(l_lo), hi = wave_max_u32(l_hi);
-        const uint32_t hdr_ref = t.lin[(uint64_t)row_ref * t.stride];
-        const uint32_t ref_node = t.lin[(uint64_t)row_ref * t.stride + BLU_ROW_NODE_BASE + lvl];
-        uint32_t d = minlen;
-        if (k != 1 && lo < hi) d = umin(minlen, shared_levels(t, lo, hi));   // levels shared by the whole top group (:137-180)
-        const uint32_t shape_ref = hdr_ref >> 8;
-        const uint32_t packed = t.codes[(uint64_t)shape_ref * t.cstride + lvl];
-        const double cut = t.cutvals[packed & ((1u << BLU_PACK_CUT_BITS) - 1u)];
-        const uint32_t codes = packed_rank(packed) | (packed_mar(packed) << 16);
-        const uint32_t ref_row = (uint32_t)start + pos_ref;
-        if (k == 1) {   // find_single_query_consensus.rs:74-150
-            const uint64_t A = __ballot(in_l && pid_ref >= cut);
-            if (A == 0) { if (lane == 0) store_status(out, q, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, ref_row); continue; }
-            const uint32_t last = (uint32_t)last_lane(A);
-            const uint32_t ident_node = (uint32_t)rl((int)ref_node, (int)last);
-            const uint32_t reached = (uint32_t)rl((int)codes, (int)last) & 0xFFFF;
-            if (lane == 0) store_result(out, q, BLU_ST_CONSENSUS_SINGLE, 0, last, BLU_NONE_U8, reached, BLU_NONE_U16, ident_node, ref_row, A, pid_ref);
-            continue;
-        }
-        const bool agree = d >= minlen;
-        if (!agree && d == 0) { if (lane == 0) store_status(out, q, BLU_ST_ERR_ROOT_DISAGREE, ref_row); continue; }
-        const uint32_t b = agree ? minlen - 1 : d - 1;
-        double max_pid = 0.0;
-        if (!agree) max_pid = wave_max_f64(l_maxpid);   // fold(0.0, |acc, i| if i > acc {i} else {acc})
-        const double ident = agree ? pid_ref : max_pid;
-        const uint64_t F = __ballot(in_l && ident >= cut);
-        const uint64_t NG = __ballot(in_l && !(ident > cut));
-        uint64_t A = F;
-        if (!agree) {
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(F >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F, 0u));
-            A = __ballot(((F >> lane) & 1) && before <= b);
-        }
-        const uint32_t last = A ? (uint32_t)last_lane(A) : b;
-        const uint32_t ident_node = (uint32_t)rl((int)ref_node, (int)last);
-        const uint32_t reached = (uint32_t)rl((int)codes, (int)last) & 0xFFFF;
-        uint32_t mar_level = BLU_NONE_U8, mar_code = BLU_NONE_U16, flags = agree ? BLU_FLAG_AGREE : 0u;
-        if (NG) {
-            mar_level = (uint32_t)first_lane(NG);
-            mar_code = ((uint32_t)rl((int)codes, (int)mar_level)) >> 16;
-            if (mar_code != ((uint32_t)rl((int)codes, (int)b) & 0xFFFF)) flags |= BLU_FLAG_MUTATED;
-        }
-        if (lane == 0) store_result(out, q, BLU_ST_CONSENSUS_MULTI, flags, b, mar_level, reached, mar_code, ident_node, ref_row, A, ident);
-    }
+    const int lane = lane_id();
+    for (uint32_t wi = wave; wi < n_work; wi += n_waves) consensus_of_long_query<STRAT, LAYOUT>(h, t, out, worklist[wi], slot, lane);
 }
 
 // ===============================================================================
@@ -2129,7 +2172,12 @@ void consensus_last_geometry(uint32_t* grid, uint32_t* block) {
 
 template <int STRAT, int LAYOUT>
 static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hipStream_t s, int num_cus,
-                    uint32_t* worklist, uint32_t* work_count, uint32_t* kind_dev, uint32_t known_kind) {
+                    uint32_t* worklist, uint32_t* work_count, uint32_t* kind_dev, uint32_t known) {
+    // known: bits 0..1 = the stream kernel kind the table wants (1 ring, 2 no ring, 0 = classify on the device), bit 2 = the
+    // table's last run left next to nothing for the worklist kernel: it is not launched (kernel A's last block drains the queue)
+    const uint32_t known_kind = known & 3u;
+    const bool no_long = (known & 4u) != 0u && (known_kind == 1u || known_kind == 2u);
+    uint32_t* const host_len = kind_dev ? kind_dev + 1 : nullptr;
     const uint64_t n_tasks = (hits.n_queries + WAVE - 1) / WAVE;
     const uint32_t cus = (uint32_t)(num_cus > 0 ? num_cus : 256);
     if (known_kind != 1u && known_kind != 2u) {
@@ -2140,24 +2188,24 @@ static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hip
     }
     // one block per CU of either kind (LDS: 12 waves with the ring, 16 without); with both in the stream, the kind that
     // was not picked for this table returns at once
-    const uint32_t forced = (known_kind == 1u || known_kind == 2u) ? 1u : 0u;
+    const uint32_t forced = ((known_kind == 1u || known_kind == 2u) ? 1u : 0u) | (no_long ? 2u : 0u);
     if (known_kind != 2u) {
         const uint64_t want = (n_tasks + WAVES_A - 1) / WAVES_A;
         const uint32_t grid = (uint32_t)(want < cus ? (want ? want : 1) : cus);
         g_grid = grid;
         g_block = BLOCK_A;
-        hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT, true>), dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count, forced);
+        hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT, true>), dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count, forced, host_len);
     }
     if (known_kind != 1u) {
         constexpr uint32_t block_n = (LAYOUT == 0 || LAYOUT == 3) ? BLOCK_A : BLOCK_N;
         const uint64_t want = (n_tasks + (block_n / WAVE) - 1) / (block_n / WAVE);
         const uint32_t grid = (uint32_t)(want < cus ? (want ? want : 1) : cus);
         if (known_kind == 2u) { g_grid = grid; g_block = block_n; }
-        hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT, false>), dim3(grid), dim3(block_n), 0, s, hits, tax, out, worklist, work_count, forced);
+        hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT, false>), dim3(grid), dim3(block_n), 0, s, hits, tax, out, worklist, work_count, forced, host_len);
     }
     // 32 waves per CU: the kernel is latency-bound per query (block size 256 / 512 / 1024: 1.11 / 1.135 / 1.14 ms on C5)
     const uint32_t grid_b = (uint32_t)(num_cus > 0 ? num_cus : 256) * (2048u / BLOCK_B);
-    hipLaunchKernelGGL((blu_consensus_long_kernel<STRAT, LAYOUT>), dim3(grid_b), dim3(BLOCK_B), 0, s, hits, tax, out, worklist, work_count);
+    if (!no_long) hipLaunchKernelGGL((blu_consensus_long_kernel<STRAT, LAYOUT>), dim3(grid_b), dim3(BLOCK_B), 0, s, hits, tax, out, worklist, work_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("kernel launch failed: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
     return BLU_OK;

@@ -174,8 +174,16 @@ struct Db {
     std::vector<std::string> node_ident;     // node id -> identifier string
     std::unordered_map<std::string, uint16_t> rank_ids;
     std::unordered_map<std::string, uint32_t> node_ids;   // key: Display(rank) + '\x1f' + identifier
-    TaxidMap row_of;
-    int64_t dup_taxid = INT64_MIN;           // first taxid seen twice while loading (refused: see add_lineage)
+    TaxidMap row_of;                         // taxid -> its (first) row
+    // taxids listed more than once -> all their rows in file order.  The reference's polars left join (mod.rs:72-76) emits one
+    // joined row per matching taxonomy row, so every hit of such a subject appears once per listing (load_hits does the same).
+    std::unordered_map<int64_t, std::vector<uint32_t>> dup_rows;
+    void note_row(int64_t taxid, uint32_t row) {
+        if (row_of.emplace(taxid, row)) return;
+        auto& v = dup_rows[taxid];
+        if (v.empty()) v.push_back(row_of.find_or(taxid, 0));
+        v.push_back(row);
+    }
 };
 
 std::string canonical_display(const std::string& raw) {
@@ -219,10 +227,7 @@ void add_lineage(Db& db, int64_t taxid, const std::string& lineage) {
     }
     if (bad) { db.lin_node.resize(first); db.lin_rank.resize(first); }
     db.bad.push_back(bad ? 1 : 0);
-    // The reference joins with polars (mod.rs:72-76): a taxid listed twice would DUPLICATE every hit row of that subject
-    // (and so change top groups and `occurrences`).  blutils databases list a taxid once; one that does not is refused
-    // rather than joined differently from the reference.
-    if (!db.row_of.emplace(taxid, (uint32_t)db.taxid.size()) && db.dup_taxid == INT64_MIN) db.dup_taxid = taxid;
+    db.note_row(taxid, (uint32_t)db.taxid.size());
     db.taxid.push_back(taxid);
     db.lin_off.push_back(db.lin_node.size());
 }
@@ -298,8 +303,7 @@ int load_db_cache(const MappedFile& f, bool use_taxid, Db& db) {
     db.node_ident.resize(h.n_nodes);
     for (uint64_t i = 0; i < h.n_nodes; ++i) db.node_ident[i].assign(nbytes + noff[i], noff[i + 1] - noff[i]);
     db.row_of.reserve(h.n_tax);
-    for (uint64_t i = 0; i < h.n_tax; ++i)
-        if (!db.row_of.emplace(db.taxid[i], (uint32_t)i)) { set_error("taxonomy cache: taxid %lld is listed more than once (the reference's left join would duplicate its hit rows)", (long long)db.taxid[i]); return BLU_ERR_PARSE; }
+    for (uint64_t i = 0; i < h.n_tax; ++i) db.note_row(db.taxid[i], (uint32_t)i);
     return BLU_OK;
 }
 
@@ -376,7 +380,6 @@ int load_db(const char* path, bool use_taxid, Db& db) {
         } while (j.ok && j.eat(','));
     }
     if (!j.ok || !found) { set_error("Unexpected error detected on parse `taxonomies` as json (offset %zu)", (size_t)(j.p - f.data)); return BLU_ERR_PARSE; }
-    if (db.dup_taxid != INT64_MIN) { set_error("taxonomies file: taxid %lld is listed more than once (the reference's left join would duplicate its hit rows)", (long long)db.dup_taxid); return BLU_ERR_PARSE; }
     return BLU_OK;
 }
 
@@ -589,6 +592,11 @@ void parse_chunk(Chunk& c, const Db& db, const char* path) {
             if (r.tax == BLU_UNMATCHED_TAXID) ++c.unmatched;
             r.bs = (int32_t)bs_t; r.aln = (int32_t)aln; r.pid = pid;
             c.rows.push_back(r);
+            if (!db.dup_rows.empty()) {                                  // a subject listed m times: m joined rows, in the DB's order
+                auto dit = db.dup_rows.find(taxid_i);
+                if (dit != db.dup_rows.end())
+                    for (size_t k = 1; k < dit->second.size(); ++k) { r.tax = dit->second[k]; c.rows.push_back(r); ++c.q_count[last_q]; }
+            }
         }
         p = nl ? nl + 1 : c.end;
     }
@@ -624,7 +632,8 @@ int load_hits(const char* path, const Db& db, HitTable& ht, int device = -1, boo
         const int fd = ::open(path, O_RDONLY);
         if (fd < 0 || fstat(fd, &sb) != 0) { if (fd >= 0) ::close(fd); set_error("Unexpected error occurred on load table: %s", path); return BLU_ERR_IO; }
         const size_t fsize = (size_t)sb.st_size;
-        const bool want_gpu = device >= 0 && !(mode && strcmp(mode, "cpu") == 0) && (fsize >= (1u << 20) || (mode && strcmp(mode, "gpu") == 0));
+        // (a DB that lists a taxid more than once multiplies hit rows in the join: the CPU parser does that)
+        const bool want_gpu = device >= 0 && db.dup_rows.empty() && !(mode && strcmp(mode, "cpu") == 0) && (fsize >= (1u << 20) || (mode && strcmp(mode, "gpu") == 0));
         int rc = BLU_INGEST_FALLBACK;
         std::string why;
         if (want_gpu) rc = load_hits_gpu(fd, fsize, db.row_of, device, host_columns, ht, &why);

@@ -8,7 +8,8 @@ What the columns are (reference: core/src/use_cases/build_consensus_identities/m
     align_length:i64, ..., bit_score:f64 (mod.rs:226-244)
   * rows regrouped by query, queries in first-appearance order, file order kept inside a query (mod.rs:134-221)
   * bit_score truncated toward zero (mod.rs:184), quotes stripped from the two strings (mod.rs:169-176)
-  * left join on the taxid (mod.rs:72-76): row of the DB's `taxonomies` list, 0xFFFFFFFF when absent
+  * left join on the taxid (mod.rs:72-76): row of the DB's `taxonomies` list, 0xFFFFFFFF when absent; a taxid the DB lists m
+    times gives m joined rows per hit (left-row order kept, the matches in the DB's order)
   * acc_rank = rank of the accession among the distinct accessions in byte order (String::cmp,
     find_multi_taxa_consensus.rs:59-66)
 """
@@ -21,9 +22,9 @@ UNMATCHED = 0xFFFFFFFF
 
 def read_table(blast_path, db_path):
     db = json.load(open(db_path))
-    row_of = {}
+    rows_of = {}                                   # a taxid listed m times: m joined rows per hit, in the DB's order (left join)
     for i, t in enumerate(db["taxonomies"]):
-        row_of.setdefault(int(t["taxid"]), i)
+        rows_of.setdefault(int(t["taxid"]), []).append(i)
     data = open(blast_path, "rb").read()
     lines = data.split(b"\n")
     if lines and lines[-1] == b"":
@@ -40,7 +41,8 @@ def read_table(blast_path, db_path):
         pid = float(c[3].decode())
         aln = int(c[4].decode())
         bs = int(float(c[12].decode()))            # truncation toward zero
-        per_q.setdefault(q, []).append((acc, row_of.get(taxid, UNMATCHED), pid, aln, bs))
+        for trow in rows_of.get(taxid, [UNMATCHED]):
+            per_q.setdefault(q, []).append((acc, trow, pid, aln, bs))
     accs = sorted({r[0] for rows in per_q.values() for r in rows})
     rank = {a: i for i, a in enumerate(accs)}
     seg = [0]

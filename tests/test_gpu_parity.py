@@ -759,3 +759,45 @@ def test_both_builds_of_the_stream_kernel_give_the_same_records(kind, monkeypatc
                 got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy=strategy,
                                                 pident_milli=pm, packed=packed)
                 _assert_records_equal(got, exp)
+
+
+def test_a_queue_that_turns_up_after_an_empty_one_is_still_worked_off():
+    """The call after a run that left the worklist empty launches no worklist kernel (a kernel boundary is a tenth of a C4
+    slice).  If the same buffers then hold a table WITH long segments, the stream kernel's last block drains the queue
+    itself: same records as the oracle, on that call and on the ones after it (which launch the worklist kernel again)."""
+    import torch
+    tax = synth.make_taxonomy(4000, 17)
+    t = _engine_tax(tax, "custom", H.CUSTOM_16S)
+    nq = 6000
+    a = synth.make_hits(tax, nq, 5, 50, device="cuda")                         # no segment over 512 rows: empty queue
+    # table B in the same number of rows: 40 queries of 1500 / 700 rows, the others share what is left
+    rng = np.random.default_rng(2)
+    lens = np.full(nq, 1, dtype=np.int64)
+    big = rng.choice(nq, 40, replace=False)
+    lens[big] = rng.choice([700, 1500], 40)
+    rest = a.n_hits - int(lens.sum())
+    small = np.setdiff1d(np.arange(nq), big)
+    lens[small] += rng.multinomial(rest, np.ones(len(small)) / len(small))
+    assert int(lens.sum()) == a.n_hits and lens.max() <= 1500 + 200
+    seg_b = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    dev = a.as_dict("milli")
+    dev["tax_row"] = t.engine_rows(dev["tax_row"]).contiguous()
+    desc_rows = a.numpy()["tax_row"]
+    out = torch.zeros(32 * nq, dtype=torch.uint8, device="cuda")
+    h = a.numpy()
+    h["pident"] = a.pident_milli.cpu().numpy().astype(np.float64) / 1000.0
+    exp_a = H.columnar(tax, h, "custom", "relaxed", H.CUSTOM_16S)
+    for _ in range(3):                                                           # classify, then the remembered kind, no worklist kernel
+        engine.run_consensus_device(t, dev, out, strategy="relaxed")
+        torch.cuda.synchronize()
+        _assert_records_equal(engine.records_from_tensor(out), exp_a)
+    dev["seg_off"].copy_(torch.from_numpy(seg_b).to("cuda"))                     # same buffers, another table
+    hb = dict(h, seg_off=seg_b.astype(np.uint64))
+    hb["tax_row"] = desc_rows
+    exp_b = H.columnar(tax, hb, "custom", "relaxed", H.CUSTOM_16S)
+    assert int((np.diff(seg_b) > 512).sum()) == 40
+    for _ in range(3):
+        out.zero_()
+        engine.run_consensus_device(t, dev, out, strategy="relaxed")
+        torch.cuda.synchronize()
+        _assert_records_equal(engine.records_from_tensor(out), exp_b)

@@ -50,8 +50,10 @@ def _write_inputs(tmp_path, tax, hits, use_taxid=False, scramble=True, half_scor
 def _oracle_from_files(bt, tj, use_taxid, taxon, strategy, custom):
     """Independent reading of the two files -> faithful oracle."""
     db = json.load(open(tj))
-    lin = {int(t["taxid"]): (t["numericLineage"] if use_taxid else t["textLineage"]) for t in db["taxonomies"]}
-    lineages = list(dict.fromkeys(lin.values()))
+    lin = {}                                           # taxid -> its lineages, one per listing (the left join of mod.rs:72-76
+    for t in db["taxonomies"]:                         # gives one joined row per matching taxonomy row, in the DB's order)
+        lin.setdefault(int(t["taxid"]), []).append(t["numericLineage"] if use_taxid else t["textLineage"])
+    lineages = list(dict.fromkeys(s for v in lin.values() for s in v))
     lin_idx = {s: i for i, s in enumerate(lineages)}
     per_q = {}
     for line in open(bt):
@@ -61,9 +63,10 @@ def _oracle_from_files(bt, tj, use_taxid, taxon, strategy, custom):
     seg, acc_idx, accs, tax_row, pid, aln, bsc = [0], [], {}, [], [], [], []
     for qn in names:
         for c in per_q[qn]:
-            acc_idx.append(accs.setdefault(c[1], len(accs)))
-            tax_row.append(lin_idx[lin[int(c[2])]] if int(c[2]) in lin else -1)
-            pid.append(float(c[3])); aln.append(int(c[4])); bsc.append(int(float(c[12])))
+            for lineage in lin.get(int(c[2]), [None]):
+                acc_idx.append(accs.setdefault(c[1], len(accs)))
+                tax_row.append(lin_idx[lineage] if lineage is not None else -1)
+                pid.append(float(c[3])); aln.append(int(c[4])); bsc.append(int(float(c[12])))
         seg.append(len(acc_idx))
     tab = orc.HitTable(np.array(seg, np.uint64), np.array(acc_idx, np.uint32), list(accs), np.array(tax_row, np.int64),
                        lineages, np.array(pid), np.array(aln, np.int64), np.array(bsc, np.int64))
@@ -103,6 +106,37 @@ def test_c1_files_through_the_pipeline(tmp_path, golden_dir, strategy, use_taxid
         n_found += 1
         assert g["taxon"] == o["taxon"], (g["query"], g["taxon"], o["taxon"])  # every field, beans and accession order included
     assert n_found > 900
+
+
+def test_a_duplicated_taxid_gives_the_document_of_the_left_join(tmp_path):
+    """mod.rs:72-76: a taxid the DB lists twice turns every hit of that subject into two joined rows — a single top hit
+    becomes a two-row group, `occurrences` double.  Expected document: the faithful oracle fed the duplicated rows."""
+    tax = synth.make_taxonomy(2000, synth.SEEDS["C1"])
+    hits = synth.make_hits(tax, 1000, synth.SEEDS["C1"], 10, p_unmatched=0.002).numpy()
+    bt, tj, _ = _write_inputs(tmp_path, tax, hits, False)
+    db = json.load(open(tj))
+    rng = np.random.default_rng(4)
+    used = sorted({int(t) for t in hits["tax_row"] if t >= 0})
+    for t in rng.choice(used, 60, replace=False):           # the same lineage again (a plain duplicate) or another taxon's
+        e = dict(db["taxonomies"][int(t)])
+        if rng.random() < 0.5:
+            other = db["taxonomies"][int(rng.choice(used))]
+            e["textLineage"], e["numericLineage"] = other["textLineage"], other["numericLineage"]
+        db["taxonomies"].insert(int(rng.integers(0, len(db["taxonomies"]))), e)
+    open(tj, "w").write(json.dumps(db))
+    for strategy in ("relaxed", "cautious"):
+        got, stats = pipeline.build_consensus_identities(bt, tj, "bacteria", strategy, lenient=True)
+        assert stats["n_hits"] > 10000                       # the join multiplied rows
+        exp = _oracle_from_files(bt, tj, False, "bacteria", strategy, None)
+        n_found = 0
+        for g in got:
+            o = exp[g["query"]]
+            if o["status"] != orc.ST_CONSENSUS:
+                assert g["taxon"] is None, g["query"]
+                continue
+            n_found += 1
+            assert g["taxon"] == o["taxon"], (g["query"], g["taxon"], o["taxon"])
+        assert n_found > 900
 
 
 def test_binary_taxonomy_cache_gives_the_same_document(tmp_path):

@@ -114,15 +114,25 @@ def _write_db(tmp_path, n=3000, duplicate=False):
     return str(bt), str(tj)
 
 
-def test_a_taxid_listed_twice_is_refused(tmp_path):
-    """The reference joins hits and taxonomies with polars (mod.rs:72-76): a taxid listed twice would duplicate every hit
-    row of that subject.  Neither loader joins differently from that in silence: both refuse the file, and so does the
-    strict number parsing of the Int64 columns ("12.7" as align_length, "12abc" as a score)."""
+def test_a_taxid_listed_twice_multiplies_its_hit_rows_like_the_left_join(tmp_path):
+    """The reference joins hits and taxonomies with polars (mod.rs:72-76, a left join): a taxid the DB lists m times gives m
+    joined rows per hit of that subject, in the DB's order.  The ingest does the same — from the JSON and from the binary
+    cache — checked column by column against the independent reading (tests/ingest_reference.py); the strict number
+    parsing of the Int64 columns ("12.7" as align_length, "12abc" as a score) is checked below."""
+    from tests import ingest_reference as ref
     bt, tj = _write_db(tmp_path, duplicate=True)
-    with pytest.raises(N.BluError, match="listed more than once"):
-        pipeline.ingest_only(bt, tj, False)
-    with pytest.raises(N.BluError, match="listed more than once"):
-        cli.main(["cache-db", tj, str(tmp_path / "dup.blucache")])
+    exp = ref.read_table(bt, tj)
+    (tmp_path / "plain").mkdir()
+    plain = ref.read_table(bt, _write_db(tmp_path / "plain", duplicate=False)[1])
+    assert len(exp["bitscore"]) > len(plain["bitscore"])                  # the duplicated subject has hits
+    got = pipeline.ingest_columns(bt, tj, device=-1)
+    for k in ("seg_off", "bitscore", "align_len", "tax_desc_row", "acc_rank"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert np.array_equal(got["pident"].view(np.uint64), exp["pident"].view(np.uint64))
+    cache = str(tmp_path / "dup.blucache")
+    cli.main(["cache-db", tj, cache])
+    st, ck = pipeline.ingest_only(bt, cache, False)
+    assert ck == ref.checksum(exp) and st["n_hits"] == len(exp["bitscore"])
     bt, tj = _write_db(tmp_path)
     good = open(bt).read().splitlines()
     cols = good[3].split("\t")
