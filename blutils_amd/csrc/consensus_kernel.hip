@@ -103,7 +103,11 @@ __device__ uint32_t g_stamps[8192 * 16];   // [wave][16]: cycles per phase, summ
 #define LIST_CAP 208       // top-group entries per wave task (64 queries; mean ~183, sigma ~18 at geometric(0.35) groups)
 #endif
 #ifndef LIST_CAP_F64
-#define LIST_CAP_F64 160   // the same in the f64 layout (4 more bytes per entry): sized so that both layouts keep 12 waves per CU
+#define LIST_CAP_F64 232   // the same in the f64 layouts (4 more bytes per entry) with the ring: 11 waves per CU (BLOCK_F) so that a C3 task's top
+                           // rows (mean 183) fit one round — at 12 waves the list held 160 entries and most tasks took two
+#endif
+#ifndef BLOCK_F
+#define BLOCK_F 704        // f64 layouts, kernel with the ring
 #endif
 
 // ---- cross-lane helpers -----------------------------------------------------
@@ -420,7 +424,7 @@ static_assert(RING_CHUNKS <= 16, "wait_vmcnt covers 0..15 younger chunks");
 // ring's registers and LDS do not (C5: 0.626 -> 0.573 ms).  blu_classify_tasks decides per run (work_count[9]); the
 // kernel of the other kind returns at once.
 template <int STRAT, int LAYOUT, bool RING>
-__global__ __launch_bounds__((RING || LAYOUT == 0 || LAYOUT == 3) ? BLOCK_A : BLOCK_N, (RING || LAYOUT == 0 || LAYOUT == 3) ? BLU_WAVES_PER_SIMD : BLU_N_WAVES_PER_SIMD)
+__global__ __launch_bounds__((LAYOUT == 0 || LAYOUT == 3) ? (RING ? BLOCK_F : BLOCK_A) : (RING ? BLOCK_A : BLOCK_N), (RING || LAYOUT == 0 || LAYOUT == 3) ? BLU_WAVES_PER_SIMD : BLU_N_WAVES_PER_SIMD)
 void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ out, uint32_t* __restrict__ worklist, uint32_t* __restrict__ work_count,
                                  uint32_t mode, uint32_t* __restrict__ host_len) {
     // mode bit 0 ("forced"): the host launched this kind alone; bit 1 ("no worklist kernel"): no launch of kernel B follows this
@@ -430,7 +434,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     const bool no_long = (mode & 2u) != 0u;
     // PACKED: 16-byte side records (milli-percent), WIDE: 24-byte side records (f64 perc_identity in words 4, 5)
     constexpr bool PID32 = LAYOUT == 1 || LAYOUT == 2, PACKED = LAYOUT == 2, WIDE = LAYOUT == 3;
-    constexpr uint32_t BLOCK_T = (RING || !PID32) ? BLOCK_A : BLOCK_N, WAVES_T = BLOCK_T / WAVE;   // (the f64 layouts do not fit 128 VGPRs)
+    constexpr uint32_t BLOCK_T = !PID32 ? (RING ? BLOCK_F : BLOCK_A) : (RING ? BLOCK_A : BLOCK_N), WAVES_T = BLOCK_T / WAVE;   // (the f64 layouts do not fit 128 VGPRs)
     constexpr uint32_t CAP = WaveLds<!PID32, RING>::CAP;   // list entries per wave task
     // forced: the host launched this kind alone (it remembered the kind of the handle's last table); else both kinds are
     // in the stream and the one blu_classify_tasks did not pick returns
@@ -985,9 +989,14 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 if (LPQ >= 4) gk += (uint32_t)dpp<0x4E>((int)gk);
                 if (LPQ >= 8) gk += (uint32_t)dpp<0x141>((int)gk);
                 if (LPQ >= 16) gk += (uint32_t)dpp<0x140>((int)gk);
-                if (PID32 && k0 + k1 + k2 + k3 > CAP) {
-                    // ---- a DENSE step: the top rows of this step alone would not fit an empty list (many hits tie on the top
-                    // score — identical database sequences).  No list: every lane fetches the side records of ITS OWN top rows,
+#ifndef BLU_DENSE_WHEN_FULL
+#define BLU_DENSE_WHEN_FULL 1
+#endif
+                if (PID32 && (BLU_DENSE_WHEN_FULL ? !fits : k0 + k1 + k2 + k3 > CAP)) {
+                    // ---- a DENSE step: the top rows of this step do not fit what is left of the list (many hits tie on the top
+                    // score — identical database sequences; round 3: also when the steps before it have filled the list — that used
+                    // to end the round and send the rest of the task through phase 1 again: tables with the reference's real
+                    // top-group sizes 1.356 -> 1.267 ms).  No list: every lane fetches the side records of ITS OWN top rows,
                     // four requests in flight, and reduces them as they come; the lanes of a query then merge (DPP) and the
                     // result goes to the query's lane of phase 2 (ds_bpermute).  Same rule as phase 2a: the reference row is
                     // the maximum (Relaxed) / minimum (Cautious) of (length, perc_identity, align_length, accession), full ties
@@ -2190,11 +2199,12 @@ static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hip
     // was not picked for this table returns at once
     const uint32_t forced = ((known_kind == 1u || known_kind == 2u) ? 1u : 0u) | (no_long ? 2u : 0u);
     if (known_kind != 2u) {
-        const uint64_t want = (n_tasks + WAVES_A - 1) / WAVES_A;
+        constexpr uint32_t block_r = (LAYOUT == 0 || LAYOUT == 3) ? BLOCK_F : BLOCK_A;
+        const uint64_t want = (n_tasks + (block_r / WAVE) - 1) / (block_r / WAVE);
         const uint32_t grid = (uint32_t)(want < cus ? (want ? want : 1) : cus);
         g_grid = grid;
-        g_block = BLOCK_A;
-        hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT, true>), dim3(grid), dim3(BLOCK_A), 0, s, hits, tax, out, worklist, work_count, forced, host_len);
+        g_block = block_r;
+        hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT, true>), dim3(grid), dim3(block_r), 0, s, hits, tax, out, worklist, work_count, forced, host_len);
     }
     if (known_kind != 1u) {
         constexpr uint32_t block_n = (LAYOUT == 0 || LAYOUT == 3) ? BLOCK_A : BLOCK_N;
