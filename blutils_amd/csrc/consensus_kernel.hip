@@ -367,8 +367,8 @@ static_assert((RING_ROWS & RING_MASK) == 0 && RING_ROWS >= 2048u, "ring size");
 // steps per task).  Lane descriptor in the list: top-row mask | first row (13 bits) | position / RPL (3 bits) — one word with
 // the mask (top-aligned) is the first word of the list slot, the rest the second (the first row can be far into a task that
 // holds long segments).
-#define DESC_SUB_BITS 3u
-#define DESC_WORD1(RPL, row0, sub) (((row0) << DESC_SUB_BITS) | ((sub) / (RPL)))
+#define DESC_SUB_BITS 8u
+#define DESC_WORD1(RPL, row0, sub) (((row0) << DESC_SUB_BITS) | (sub))   // first row relative to the task (13 bits) | its position in the segment (< 128)
 static_assert(LIST_CAP >= 128 && LIST_CAP_F64 >= 128, "the list area also stages the 64 records of a task");
 
 template <bool F64, bool RING>
@@ -923,8 +923,13 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             if (ring_head < ring_tail) { ring_head = ring_tail; if (ring_landed < ring_tail) ring_landed = ring_tail; }
             while (ring_head < ring_end && ring_head - ring_tail < RING_CHUNKS) { ring_dma(rs_ring, ring_c0, sk_total ? ring_phys(ring_head) : ring_head, ring_head); ++ring_head; }
         };
-        auto phase1_scan = [&](const auto rpl_c, const uint32_t LPQ) {
+        // FULL (every streamed segment of the round has at least RPL rows): the lane that would run past the end of its segment
+        // takes the segment's LAST RPL rows instead — rows it shares with the lane before it are cleared from its top-row mask —
+        // so every lane that has rows has RPL of them and no row needs masking: the two instructions per row that cost went
+        // into nothing else (C3: 50-row segments, 32 rows per lane, the second lane of a query held 18).
+        auto phase1_scan = [&](const auto rpl_c, const auto full_c, const uint32_t LPQ) {
             constexpr uint32_t RPL = decltype(rpl_c)::value;
+            constexpr bool FULL = decltype(full_c)::value;
             static_assert(RPL <= RING_PAD && RPL <= 32u, "rows per lane");
             const uint32_t QPS = WAVE / LPQ;
             const uint32_t grp = (uint32_t)lane / LPQ, sub = ((uint32_t)lane & (LPQ - 1u)) * RPL, row16 = (uint32_t)lane >> 4;
@@ -949,9 +954,13 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 STAMP(10)   // (waiting for ring data)
                 const uint32_t qi = qb + grp;
                 const uint2 sg = L.seg[qi];
-                const int left = (sg.y > short_seg ? 0 : (int)sg.y) - (int)sub;      // rows of the segment from this lane's first row on
-                const uint32_t row0 = sg.x + sub;                                    // (in the column, relative to the task: what the gather reads)
-                const uint32_t a = ((uint32_t)vbase + L.vx[qi] + sub) & RING_MASK;
+                const int left0 = (sg.y > short_seg ? 0 : (int)sg.y) - (int)sub;     // rows of the segment from this lane's nominal first row on
+                // FULL: a lane with fewer than RPL rows left moves back by `over` rows, to the last RPL rows of its segment
+                const uint32_t over = (FULL && left0 > 0 && left0 < (int)RPL) ? RPL - (uint32_t)left0 : 0u;
+                const uint32_t sub_e = sub - over;                                   // position of the lane's first row in its segment
+                const int left = FULL ? (left0 > 0 ? (int)RPL : 0) : left0;          // rows the lane holds
+                const uint32_t row0 = sg.x + sub_e;                                  // (in the column, relative to the task: what the gather reads)
+                const uint32_t a = ((uint32_t)vbase + L.vx[qi] + sub_e) & RING_MASK;
                 int b[RPL];
 #pragma unroll
                 for (uint32_t i = 0; i < RPL; ++i) b[i] = (int)L.ring[a + i];
@@ -962,8 +971,14 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 for (uint32_t i = 0; i < RPL; ++i) asm volatile("" : "+v"(b[i]));
                 if (r_hi > r_lo) { ring_tail = (uint32_t)((vbase + r_hi) >> 8); ring_refill(); }
                 int M = INT_MIN;
+                if constexpr (FULL) {
 #pragma unroll
-                for (uint32_t i = 0; i < RPL; ++i) { b[i] = (int)i < left ? b[i] : INT_MIN; M = imax(M, b[i]); }
+                    for (uint32_t i = 0; i < RPL; ++i) M = imax(M, b[i]);
+                    M = left > 0 ? M : INT_MIN;                       // (a lane past the end of its segment read another query's rows)
+                } else {
+#pragma unroll
+                    for (uint32_t i = 0; i < RPL; ++i) { b[i] = (int)i < left ? b[i] : INT_MIN; M = imax(M, b[i]); }
+                }
                 if (LPQ >= 2) M = imax(M, dpp<0xB1>(M));
                 if (LPQ >= 4) M = imax(M, dpp<0x4E>(M));
                 if (LPQ >= 8) M = imax(M, dpp<0x141>(M));             // row_half_mirror
@@ -973,6 +988,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
 #pragma unroll
                 for (uint32_t i = 0; i < RPL; ++i) mask = (mask << 1) | (uint32_t)(b[i] == M);
                 mask = left > 0 ? mask : 0u;
+                if constexpr (FULL) mask &= 0xFFFFFFFFu >> (32u - RPL + over);   // rows 0 .. over - 1 are the previous lane's
                 const uint32_t c = (uint32_t)__builtin_popcount(mask);
                 uint32_t incl = c;                                    // inclusive prefix of the top-row counts inside the 16-lane row
                 incl += (uint32_t)dpp<0x111>((int)incl);
@@ -1089,7 +1105,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                             const int own = (int)((16u * g + ((uint32_t)lane >> 2)) * 4u);
                             const uint32_t o_row0 = (uint32_t)__builtin_amdgcn_ds_bpermute(own, (int)row0);
                             const uint32_t o_mask = (uint32_t)__builtin_amdgcn_ds_bpermute(own, (int)mask);
-                            const uint32_t o_sub = (uint32_t)__builtin_amdgcn_ds_bpermute(own, (int)sub);
+                            const uint32_t o_sub = (uint32_t)__builtin_amdgcn_ds_bpermute(own, (int)sub_e);
                             if (__ballot(o_mask != 0u) == 0ull) continue;
                             reset();
                             constexpr uint32_t NF = PACKED ? 4u : 2u;   // requests per lane in flight (a record of the column layout is four loads)
@@ -1126,7 +1142,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                                 const bool on = m != 0u;
                                 const uint32_t hb = on ? 31u - (uint32_t)__builtin_clz(m) : 0u, i = RPL - 1u - hb;   // (mask bit RPL - 1 - i = row i: file order)
                                 m = on ? (m & ~(1u << hb)) : 0u;
-                                gp[j] = on ? sub + i : 0xFFFFFFFFu;
+                                gp[j] = on ? sub_e + i : 0xFFFFFFFFu;
                                 rq[j] = load_record(row0 + i, on);
                             }
 #pragma unroll
@@ -1155,7 +1171,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     const uint32_t qo = qb + lane_o / LPQ;            // first query that does not fit
                     const bool taken = qi < qo;
                     if (sub == 0) L.meta[qi] = taken ? (idx | (gk << 16)) : META_SLOW;
-                    if (taken && c) { L.rec[idx].x = mask << (32u - RPL); L.rec[idx].y = DESC_WORD1(RPL, row0, sub); }
+                    if (taken && c) { L.rec[idx].x = mask << (32u - RPL); L.rec[idx].y = DESC_WORD1(RPL, row0, sub_e); }
                     fill = (uint32_t)rl((int)idx, (int)((qo - qb) * LPQ));   // where the first query left would have started
                     stop_q = qo;
                     wait_vmcnt(0u);
@@ -1168,7 +1184,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 // rows (RPL bits), its first row relative to the task (13 bits: a ring task has at most 64 x 128 rows) and its
                 // position in the segment / RPL; the slots in between stay 0 and gather_list works the entries out
                 static_assert((RPL == 16u || RPL == 32u) && SHORT_SEG <= 128u, "descriptor word of a lane");
-                if (c) { L.rec[idx].x = mask << (32u - RPL); L.rec[idx].y = DESC_WORD1(RPL, row0, sub); }
+                if (c) { L.rec[idx].x = mask << (32u - RPL); L.rec[idx].y = DESC_WORD1(RPL, row0, sub_e); }
             }
         };
         // The list entries of a ring round: lane e of a 64-entry chunk finds the lane descriptor its entry belongs to (the last
@@ -1221,7 +1237,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 }
                 i += (r >= (x >> 1)) ? 1u : 0u;
                 const uint32_t row = (d >> DESC_SUB_BITS) + i;
-                gpos[u] = (d & ((1u << DESC_SUB_BITS) - 1u)) * scan_rpl + i;
+                gpos[u] = (d & ((1u << DESC_SUB_BITS) - 1u)) + i;
                 if (PACKED) g[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, valid ? row * 16u : 0xFFFFFFC0u, 0, GATHER_AUX);
                 else if (WIDE) {
                     g[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, valid ? row * 24u : 0xFFFFFFC0u, 0, GATHER_AUX);
@@ -1334,8 +1350,12 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             if (ring_round) {
 #pragma unroll
                 for (uint32_t u = 0; u * WAVE < CAP; ++u) { const uint32_t i = u * WAVE + (uint32_t)lane; if (i < CAP) L.rec[i].x = 0u; }   // (no entry starts here)
-                if (scan_rpl == 32u) phase1_scan(std::integral_constant<uint32_t, 32>(), lpq);
-                else phase1_scan(std::integral_constant<uint32_t, 16>(), lpq);
+                // (rows of the lanes' windows may overlap only inside one segment: every streamed segment at least a window long)
+                const bool all_full = __ballot(rows != 0u && rows <= short_seg && rows < scan_rpl) == 0ull;
+                if (scan_rpl == 32u) {
+                    if (all_full) phase1_scan(std::integral_constant<uint32_t, 32>(), std::true_type(), lpq);
+                    else phase1_scan(std::integral_constant<uint32_t, 32>(), std::false_type(), lpq);
+                } else phase1_scan(std::integral_constant<uint32_t, 16>(), std::false_type(), lpq);
             }
             else if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>(), false);   // the C3 shape, specialised
             else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u), longest >= (PACKED ? 9u : 25u));   // two-stage steps: measured break-even (packed records: 10 hits -2.5 %, 20 hits -17 %; columns: 20 hits +3 %, 30 hits -6 %)
