@@ -136,6 +136,16 @@ __device__ __forceinline__ int wave_min_i32(int x) {
     ROW_REDUCE(x, imin)
     return imin(imin(rl(x, 0), rl(x, 16)), imin(rl(x, 32), rl(x, 48)));
 }
+#ifndef BLU_FLAT_PASS
+#define BLU_FLAT_PASS 1
+#endif
+#define FLAT_SEG 256u            // longest segment the flat pass takes (64 quads: one step); longer ones take the long pass
+__device__ __forceinline__ int iadd(int a, int b) { return a + b; }
+__device__ __forceinline__ int wave_sum_u32(uint32_t v) {
+    int x = (int)v;
+    ROW_REDUCE(x, iadd)
+    return rl(x, 0) + rl(x, 16) + rl(x, 32) + rl(x, 48);
+}
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return (uint32_t)wave_max_i32((int)(v ^ 0x80000000u)) ^ 0x80000000u; }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return (uint32_t)wave_min_i32((int)(v ^ 0x80000000u)) ^ 0x80000000u; }
 
@@ -371,8 +381,12 @@ static_assert((RING_ROWS & RING_MASK) == 0 && RING_ROWS >= 2048u, "ring size");
 #define DESC_WORD1(RPL, row0, sub) (((row0) << DESC_SUB_BITS) | (sub))   // first row relative to the task (13 bits) | its position in the segment (< 128)
 static_assert(LIST_CAP >= 128 && LIST_CAP_F64 >= 128, "the list area also stages the 64 records of a task");
 
+// the flat pass of the kernel without the ring (tasks of mixed segment lengths): per query its first 4-row quad in the round's
+// quad numbering, its top bit-score and its top-row count
+struct FlatLds { uint32_t qs[WAVE + 4]; int32_t qm[WAVE]; uint32_t qk[WAVE]; };
+struct NoFlatLds {};
 template <bool F64, bool RING>
-struct WaveLds {
+struct WaveLds : std::conditional_t<RING, NoFlatLds, FlatLds> {
     static constexpr uint32_t CAP = F64 ? LIST_CAP_F64 : LIST_CAP;
     alignas(16) uint32_t ring[RING ? RING_ROWS + RING_PAD : 4u];   // bit-scores: row v sits at ring[v & RING_MASK]; the pad mirrors ring[0 .. RING_PAD) so that a lane's run of rows never wraps
     // top-group rows of the task's queries in file order: {engine row id (sorted position | length << BLU_ROW_BITS),
@@ -903,6 +917,122 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 }
             }
         };
+        // ---------------- phase 1, FLAT pass (kernel without the ring): lanes dealt to the queries by need ----------------
+        // A task of mixed segment lengths (Zipf-like hit counts) wastes most lanes of the passes above: every streamed query
+        // pays the lanes of the widest one, and each longer one takes half a step of its own.  Here the rows of the round's
+        // queries of up to FLAT_SEG rows are cut into quads of 4 consecutive rows, numbered through the task; a step takes as
+        // many WHOLE queries as its 64 lanes hold quads for, lane l the l-th quad of the step, of whichever query owns it
+        // (binary search over the queries' first quads, in LDS).  The query's top bit-score meets in LDS (atomic max over its
+        // lanes), the top rows get their list slots by a scan over the step — quad order is file order — and the other values
+        // are fetched for the top rows only.  The bit-scores of step s + 1 are requested before step s is worked on.
+        // Roughly rows / 256 / 0.8 steps per task instead of one per 2 .. 16 queries; longer segments keep the long pass.
+        auto phase1_flat = [&]() {
+            if constexpr (!RING) {
+            const uint32_t rows_all = L.seg[lane].y;             // this lane's query: 0 = nothing to do in this round
+            const uint32_t rows = rows_all <= FLAT_SEG ? rows_all : 0u;
+            const uint32_t nquad = (rows + 3u) >> 2;
+            uint32_t incl = nquad;
+            incl += (uint32_t)dpp<0x111>((int)incl);
+            incl += (uint32_t)dpp<0x112>((int)incl);
+            incl += (uint32_t)dpp<0x114>((int)incl);
+            incl += (uint32_t)dpp<0x118>((int)incl);
+            const uint32_t t0 = (uint32_t)rl((int)incl, 15), t1 = (uint32_t)rl((int)incl, 31), t2 = (uint32_t)rl((int)incl, 47);
+            const uint32_t r16 = (uint32_t)lane >> 4;
+            incl += r16 == 0 ? 0u : (r16 == 1 ? t0 : (r16 == 2 ? t0 + t1 : t0 + t1 + t2));
+            const uint32_t q_end = incl, q_begin = incl - nquad;   // this query's quads in the round's numbering
+            L.qs[lane] = q_begin;
+            L.qm[lane] = INT_MIN;
+            L.qk[lane] = 0u;
+            if (rows != 0u) L.meta[lane] = META_SLOW;            // until the query is complete in the list
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            struct Quad { uint32_t q, oq, voff; int left; };
+            struct Step { uint32_t qb, S, n; };                  // queries [qa, qb), first quad, quads
+            // the step that starts at query qa: the whole queries whose quads end within 64 of its first quad (a contiguous
+            // range: the prefix sums do not decrease; one query never has more than 64 quads)
+            auto compose = [&](const uint32_t qa) {
+                Step T;
+                T.S = qa < WAVE ? (uint32_t)rl((int)q_begin, (int)qa) : 0u;
+                const uint64_t in = qa < WAVE ? (__ballot((uint32_t)lane >= qa && q_end <= T.S + WAVE) >> qa) : 0ull;
+                const uint32_t cnt = in == ~0ull ? WAVE : (uint32_t)__builtin_ctzll(~in);   // leading run of ones
+                T.qb = qa + cnt;
+                T.n = cnt ? (uint32_t)rl((int)q_end, (int)(T.qb - 1u)) - T.S : 0u;
+                return T;
+            };
+            auto quad_of = [&](const Step& T) {                  // lane's quad of the step: owner = the last query whose first quad is <= it
+                Quad Q;
+                const uint32_t g = T.S + (uint32_t)lane;
+                uint32_t q = 0;
+#pragma unroll
+                for (uint32_t st = 32; st; st >>= 1) { const uint32_t c = q + st; if (L.qs[c] <= g) q = c; }
+                const uint2 sg = L.seg[q];
+                Q.q = q;
+                Q.oq = g - L.qs[q];
+                Q.left = (uint32_t)lane < T.n ? (int)umin(sg.y, FLAT_SEG) - (int)(4u * Q.oq) : 0;
+                Q.voff = Q.left > 0 ? (sg.x + 4u * Q.oq) * 4u : 0xFFFFFFF0u;
+                return Q;
+            };
+            uint32_t running = fill, q_cut = WAVE, qa = 0;
+            Step T = compose(qa);
+            while (T.n == 0u && T.qb < WAVE && T.qb > qa) { qa = T.qb; T = compose(qa); }   // (leading queries without rows)
+            Quad Q = quad_of(T);
+            StepRegs R;
+            R.vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, Q.voff, 0, STREAM_AUX);
+            while (T.n != 0u) {
+                // the next step's bit-scores travel while this one is worked on
+                uint32_t qn = T.qb;
+                Step TN = compose(qn);
+                while (TN.n == 0u && TN.qb < WAVE && TN.qb > qn) { qn = TN.qb; TN = compose(qn); }
+                Quad QN;
+                u32x4 vbn = {0u, 0u, 0u, 0u};
+                if (TN.n != 0u) { QN = quad_of(TN); vbn = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, QN.voff, 0, STREAM_AUX); }
+                else { QN.q = 0; QN.oq = 0; QN.voff = 0xFFFFFFF0u; QN.left = 0; }
+                asm volatile("" ::"v"(R.vbs));
+                const int b0 = Q.left > 0 ? (int)R.vbs.x : INT_MIN, b1 = Q.left > 1 ? (int)R.vbs.y : INT_MIN;
+                const int b2 = Q.left > 2 ? (int)R.vbs.z : INT_MIN, b3 = Q.left > 3 ? (int)R.vbs.w : INT_MIN;
+                if (Q.left > 0) atomicMax(&L.qm[Q.q], imax(imax(b0, b1), imax(b2, b3)));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const int M = L.qm[Q.q];
+                const bool t0b = Q.left > 0 && b0 == M, t1b = Q.left > 1 && b1 == M, t2b = Q.left > 2 && b2 == M, t3b = Q.left > 3 && b3 == M;
+                const uint32_t tmask = (uint32_t)t0b | ((uint32_t)t1b << 1) | ((uint32_t)t2b << 2) | ((uint32_t)t3b << 3);
+                const uint32_t c = (uint32_t)__builtin_popcount(tmask);
+                uint32_t in2 = c;
+                in2 += (uint32_t)dpp<0x111>((int)in2);
+                in2 += (uint32_t)dpp<0x112>((int)in2);
+                in2 += (uint32_t)dpp<0x114>((int)in2);
+                in2 += (uint32_t)dpp<0x118>((int)in2);
+                const uint32_t k0 = (uint32_t)rl((int)in2, 15), k1 = (uint32_t)rl((int)in2, 31), k2 = (uint32_t)rl((int)in2, 47), k3 = (uint32_t)rl((int)in2, 63);
+                in2 += r16 == 0 ? 0u : (r16 == 1 ? k0 : (r16 == 2 ? k0 + k1 : k0 + k1 + k2));
+                const uint32_t idx0 = running + in2 - c;          // list slot of this lane's first top row
+                if (Q.left > 0 && Q.oq == 0u) L.meta[Q.q] = META_SLOW | idx0;   // the query's first slot (under the flag until the query is complete)
+                if (c) atomicAdd(&L.qk[Q.q], c);
+                const bool over = Q.left > 0 && idx0 + c > CAP;
+                const uint64_t over_m = __ballot(over);
+                const bool room = !over && c != 0u && (over_m == 0ull || (uint32_t)lane < (uint32_t)__builtin_ctzll(over_m));
+                fetch_rest(R, Q.voff, room ? tmask : 0u);
+                uint32_t idx = idx0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (room && ((tmask >> r) & 1u)) { put_entry(idx, R, r, 4u * Q.oq + (uint32_t)r); ++idx; }
+                }
+                if (over_m) { q_cut = (uint32_t)rl((int)Q.q, __builtin_ctzll(over_m)); break; }   // the list is full: from this query on, the next round
+                running += k0 + k1 + k2 + k3;
+                T = TN; Q = QN; R.vbs = vbn;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // lane = query again: complete queries get {first slot, top-row count}; the one the list filled up in and those
+            // behind it stay marked for the next round (a query larger than the whole list makes no progress: worklist)
+            const uint32_t m = L.meta[lane];
+            if (rows != 0u && (uint32_t)lane < q_cut) L.meta[lane] = (m & 0xFFFFu) | (L.qk[lane] << 16);
+            fill = q_cut < WAVE ? (L.meta[q_cut] & 0xFFFFu) : running;
+            if (q_cut < WAVE) stop_q = q_cut;                    // (the long pass of this round is left out too)
+            }
+        };
         // ---------------- phase 1 of a ring task: lane = RPL consecutive rows, read from the LDS ring ----------------
         // A step takes 64 / LPQ queries, LPQ = 1, 2, 4 or 8 lanes per query by the task's longest segment (<= 16 RPL / 8 = 128
         // rows); a lane scans its rows one after the other — the bit-scores are in LDS, so a per-lane address costs
@@ -1322,7 +1452,34 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 if (c16 < best) { best = c16; short_seg = 16u; }
             }
 #endif
-            const uint32_t longest = wave_max_u32(rows > short_seg ? 0u : rows);   // longest streamed segment of the task
+            // Kernel without the ring: a round of mixed lengths takes the flat pass when its quads (twice: two passes) are fewer
+            // lane-steps than the cheapest width of the passes above plus their long pass
+            bool flat_round = false;
+            if constexpr (!RING) {
+                const uint32_t n128 = (uint32_t)__builtin_popcountll(__ballot(rows != 0u && rows <= SHORT_SEG));
+                const uint32_t n_over = (uint32_t)__builtin_popcountll(__ballot(rows > SHORT_SEG));
+                uint32_t best;
+                {
+                    const uint32_t n16 = (uint32_t)__builtin_popcountll(__ballot(rows != 0u && rows <= 16u));
+                    const uint32_t n32 = (uint32_t)__builtin_popcountll(__ballot(rows != 0u && rows <= 32u));
+                    const uint32_t n64 = (uint32_t)__builtin_popcountll(__ballot(rows != 0u && rows <= 64u));
+                    best = 32u * n128;
+                    best = umin(best, 16u * n64 + BLU_LONG_COST * (n128 - n64));
+                    best = umin(best, 8u * n32 + BLU_LONG_COST * (n128 - n32));
+                    best = umin(best, 4u * n16 + BLU_LONG_COST * (n128 - n16));
+                }
+                uint32_t quads = rows <= FLAT_SEG ? (rows + 3u) >> 2 : 0u;
+                quads = (uint32_t)wave_sum_u32(quads);
+                // (flat: its quads once, at ~80 % of the lanes, + the long pass of the segments over FLAT_SEG rows)
+                const uint32_t n_flat_long = (uint32_t)__builtin_popcountll(__ballot(rows > FLAT_SEG));
+                // and only where short queries dominate (a mean of at most 64 rows): its steps cost more than a streamed step, which
+                // tables of mid-sized segments (uniform 1 .. 200 rows) do not earn back
+                const uint32_t n_live = (uint32_t)__builtin_popcountll(__ballot(rows != 0u));
+                flat_round = BLU_FLAT_PASS && quads != 0u && quads <= 16u * n_live &&
+                             quads + quads / 4u + 64u + BLU_LONG_COST * n_flat_long < best + BLU_LONG_COST * n_over;
+                if (flat_round) short_seg = FLAT_SEG;
+            }
+            const uint32_t longest = flat_round ? 0u : wave_max_u32(rows > short_seg ? 0u : rows);   // longest streamed segment of the task
             // (BLU_MIXED_RING: tasks that also hold longer segments through the ring, their whole chunks left out — correct
             // (full GPU suite green with it) but no gain on C5, whose steps shrink to a few queries each: off)
             ring_round = RING && contiguous && longest != 0u && (all_short ? __ballot(rows > short_seg) == 0ull : (bool)BLU_MIXED_RING);
@@ -1357,6 +1514,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     else phase1_scan(std::integral_constant<uint32_t, 32>(), std::false_type(), lpq);
                 } else phase1_scan(std::integral_constant<uint32_t, 16>(), std::false_type(), lpq);
             }
+            else if (flat_round) phase1_flat();
             else if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>(), false);   // the C3 shape, specialised
             else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u), longest >= (PACKED ? 9u : 25u));   // two-stage steps: measured break-even (packed records: 10 hits -2.5 %, 20 hits -17 %; columns: 20 hits +3 %, 30 hits -6 %)
             // queries phase 1 did not get to (the list filled up): marked for the next round, long ones included
