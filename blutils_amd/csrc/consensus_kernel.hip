@@ -1324,11 +1324,11 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         auto gather_list = [&](auto&& between) {
             constexpr int NG = (CAP + WAVE - 1) / WAVE;
             u32x4 g[NG];
-            uint32_t ghi[NG], gpos[NG];
+            uint32_t ghi[NG], gpos[NG], ghint[NG];
             uint32_t carry = 0;                                        // slot of the last descriptor seen so far (slot 0 always holds one)
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
-                g[u] = u32x4{0u, 0u, 0u, 0u}; ghi[u] = 0u; gpos[u] = 0u;
+                g[u] = u32x4{0u, 0u, 0u, 0u}; ghi[u] = 0u; gpos[u] = 0u; ghint[u] = 0u;
                 if ((uint32_t)u * WAVE >= fill_ring) continue;             // (wave-uniform)
                 const uint32_t idx = (uint32_t)u * WAVE + (uint32_t)lane;
                 const bool valid = idx < fill_ring;
@@ -1372,7 +1372,8 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 else if (WIDE) {
                     g[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, valid ? row * 24u : 0xFFFFFFC0u, 0, GATHER_AUX);
                     const u32x2 p = __builtin_amdgcn_raw_buffer_load_b64(rs_tax, valid ? row * 24u + 16u : 0xFFFFFFE0u, 0, GATHER_AUX);
-                    g[u].y = p.x; ghi[u] = p.y;   // (the shape hint in word 1 is not carried through the list of this layout)
+                    ghint[u] = g[u].y;             // (word 1: the shape hint << 17)
+                    g[u].y = p.x; ghi[u] = p.y;
                 } else {
                     const uint32_t o4 = valid ? row * 4u : 0xFFFFFFF0u;
                     g[u].x = __builtin_amdgcn_raw_buffer_load_b32(rs_tax, o4, 0, GATHER_AUX);
@@ -1390,20 +1391,34 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             // perc_identity) as ONE word (length << 17 | milli-percent: the first two sort keys of
             // find_multi_taxa_consensus.rs:39-68), align_length biased to compare unsigned.  A perc_identity that does not
             // fit 17 bits (> 131 %: not BLAST output) keeps the round on the plain records.
+            // f64 layouts: the same, when every perc_identity of the round is an exact milli-percent value k / 1000 below
+            // 131.071 (what BLAST prints): k = round(p * 1000) is taken only if the engine's own k / 1000.0 gives p back bit for
+            // bit, so the integer compares order the hits as the f64 compares would and the identity the record carries is p.
             bool ovf = false;
-            if (PID32) {
+            uint32_t gk[NG];
 #pragma unroll
-                for (int u = 0; u < NG; ++u) ovf |= !PACKED && ((uint32_t)u * WAVE + (uint32_t)lane < fill_ring) && g[u].y >= (1u << KEY_PID_BITS);
+            for (int u = 0; u < NG; ++u) {
+                const bool valid = (uint32_t)u * WAVE + (uint32_t)lane < fill_ring;
+                if constexpr (PID32) { gk[u] = g[u].y & PM_MASK; ovf |= !PACKED && valid && g[u].y >= (1u << KEY_PID_BITS); }
+                else {
+                    const double p = __hiloint2double((int)ghi[u], (int)g[u].y);
+                    const bool in_range = p >= 0.0 && p < 131.0705;
+                    const uint32_t k = in_range ? (uint32_t)(p * 1000.0 + 0.5) : 0u;
+                    const double back = milli_to_f64(k);
+                    gk[u] = k;
+                    ovf |= valid && !(in_range && __double2hiint(back) == (int)ghi[u] && __double2loint(back) == (int)g[u].y && k < BLU_KTHR_NEVER);
+                }
             }
-            keyed = PID32 && __ballot(ovf) == 0ull && fill == fill_ring;   // (entries appended by the long pass are plain records)
+            keyed = __ballot(ovf) == 0ull && fill == fill_ring;   // (entries appended by the long pass are plain records)
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
                 const uint32_t idx = (uint32_t)u * WAVE + (uint32_t)lane;
                 if (idx < fill_ring) {
                     if (keyed) {
-                        const uint32_t len = umin(g[u].x >> BLU_ROW_BITS, t.max_depth), hint = g[u].y >> KEY_PID_BITS;   // (hint: packed layout only, else 0)
+                        const uint32_t len = umin(g[u].x >> BLU_ROW_BITS, t.max_depth);
+                        const uint32_t hint = (PID32 ? g[u].y : ghint[u]) >> KEY_PID_BITS;   // (the layouts with side records; else 0)
                         L.rec[idx] = make_uint4((g[u].x & ROW_MASK) | ((hint >> 8) << BLU_ROW_BITS),
-                                                (len << KEYED_LEN_SHIFT) | ((g[u].y & PM_MASK) << KEYED_PID_SHIFT) | (hint & 0xFFu), g[u].z ^ 0x80000000u, g[u].w);
+                                                (len << KEYED_LEN_SHIFT) | (gk[u] << KEYED_PID_SHIFT) | (hint & 0xFFu), g[u].z ^ 0x80000000u, g[u].w);
                     } else L.rec[idx] = make_uint4(g[u].x, g[u].y, g[u].z, g[u].w);
                     L.pq[idx] = (uint16_t)gpos[u];
                     if (!PID32) L.p1[idx] = ghi[u];
@@ -1589,8 +1604,10 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             const uint32_t last_e = k ? k - 1u : 0u;
             uint4 nx_rec = make_uint4(0, 0, 0, 0);
             uint32_t nx_pq = 0;
-            if (!(PID32 && keyed)) { nx_rec = L.rec[first]; nx_pq = L.pq[first]; }   // (generic loop: entry e + 1 is read while entry e is worked on)
-            if (PID32 && keyed) {
+            uint32_t l_keyed = 0;                        // 1: the lane's result comes from comparison-ready entries (identities = exact milli-percent)
+            if (!keyed) { nx_rec = L.rec[first]; nx_pq = L.pq[first]; }   // (generic loop: entry e + 1 is read while entry e is worked on)
+            if (keyed) {
+                l_keyed = 1u;
                 uint64_t BK = 0;                         // best (length, perc_identity, align_length) so far
                 uint32_t kmin = 0xFFFFFFFFu, pmax = 0;
                 uint32_t l_x = 0, l_y = 0;               // .x / .y of the entry taken last: its position and shape hint come out after the loop
@@ -1634,6 +1651,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 l_row = l_x & ROW_MASK;
                 l_hint = ((l_x >> BLU_ROW_BITS) << 8) | (l_y & 0xFFu);
                 if constexpr (PID32) { b_pid = (k1 >> KEYED_PID_SHIFT) & PM_MASK; l_maxpid = pmax; }
+                else { b_pid = milli_to_f64((k1 >> KEYED_PID_SHIFT) & PM_MASK); l_maxpid = milli_to_f64(pmax); }   // (the doubles they came from, bit for bit)
             } else {
                 for (uint32_t e = 0; e < kmax; ++e) {
                     const uint4 x = nx_rec;              // {row id, pident, align_len, accession rank}
@@ -1678,7 +1696,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 else if (err) { pack_status(ra, rb, err, row0 + err_pos); rec_kind = 1; }
                 else if (!PID32 && nan_pos != 0xFFFFFFFFu) { pack_status(ra, rb, BLU_ST_ERR_BAD_PIDENT, row0 + nan_pos); rec_kind = 1; }
                 else {
-                    r_len = b_len | (l_hint << 8); r_pid = b_pid; r_row = l_row; r_pos = l_pos; minlen = l_minlen; max_pid = l_maxpid;
+                    r_len = b_len | (l_hint << 8) | (l_keyed << 30); r_pid = b_pid; r_row = l_row; r_pos = l_pos; minlen = l_minlen; max_pid = l_maxpid;
                     mode = k == 1 ? 2u : 0u;
                     g_lo = lo; g_hi = hi;    // span of the group in sorted order: phase 2c turns it into the shared levels
                 }
@@ -1700,7 +1718,8 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         else if (mode != 3) {
             const bool single = mode == 2;
             rec_kind = 1;
-            const uint32_t r_hint = r_len >> 8;
+            const uint32_t r_hint = (r_len >> 8) & ((1u << BLU_HINT_BITS) - 1u);
+            const bool r_keyed = (r_len >> 30) != 0u;   // f64 layouts: the identities of this query's top rows are exact milli-percent values
             r_len &= 0xFFu;
             // The reference row: header, neighbour run lengths of 20 levels and the node ids in one 128-byte line (up to 20
             // levels), read with eight 16-byte loads issued back to back: one memory request.  (Reading the node id
@@ -1732,7 +1751,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             // lane whose hint is missing or wrong asks again with the shape the row gives.
             uint4 ck[4] = {};
             uint32_t shape_req = 0xFFFFFFFFu;
-            if constexpr (PACKED) {
+            if constexpr (PACKED || WIDE) {
                 if (r_hint) {   // (no hint — more shapes than the hint has room for, a record put together by hand, a dense step: below)
                     shape_req = umin(r_hint - 1u, t.n_shapes - 1u);
                     const uint4* kg = reinterpret_cast<const uint4*>(t.kthr + (uint64_t)shape_req * t.cstride);
@@ -1792,8 +1811,9 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 // 131.071 % and more (not BLAST output; the packed layout cannot hold them) take the f64 tests.
                 uint32_t ident_k = 0;
                 if constexpr (PID32) ident_k = (single | agree) ? r_pid : max_pid;
+                else ident_k = r_keyed ? (uint32_t)(ident * 1000.0 + 0.5) : BLU_KTHR_NEVER;   // (exact: ident is k / 1000.0 for that k)
                 if constexpr (PACKED) ident_k = umin(ident_k, BLU_KTHR_NEVER - 1u);   // (records put together by hand with the one value blu_hits_pack refuses)
-                const bool by_k = PACKED || (PID32 && __ballot(ident_k >= BLU_KTHR_NEVER) == 0ull);
+                const bool by_k = PACKED || __ballot(ident_k >= BLU_KTHR_NEVER) == 0ull;
                 // linnaean_ranks.rs:174-212 + build_blast_consensus_identity.rs:67-82
                 uint64_t F = 0, A = 0;
                 uint32_t mar_level = BLU_NONE_U8, nF = 0;
@@ -1802,9 +1822,9 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 // since phase 2a; the records are staged there afterwards), 16 words per lane, so that "the word of level j"
                 // with j different in every lane is one LDS read instead of a 16-way select chain over the registers
                 uint32_t* const stage = reinterpret_cast<uint32_t*>(&L.rec[0]) + (uint32_t)lane * 16u;
-                if constexpr (PID32) {
+                {
                   if (by_k) {
-                    if (!PACKED || shape != shape_req) {       // no hint, or not the row's shape: the words of the shape the row gives
+                    if (!(PACKED || WIDE) || shape != shape_req) {       // no hint, or not the row's shape: the words of the shape the row gives
 #pragma unroll
                         for (int k = 0; k < 4; ++k) ck[k] = lvl4[k];
                     }

@@ -10,7 +10,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 cat blutils_amd/csrc/consensus_kernel.hip blutils_amd/csrc/blu_internal.h | sha256sum | cut -d' ' -f1 > "$out/kernel_sha256.txt"
 echo "$*" > "$out/bench_args.txt"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py "$@" > "$out/bench_under_trace.json" 2> "$out/bench_under_trace.log"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --no-secondary "$@" > "$out/bench_under_trace.json" 2> "$out/bench_under_trace.log"
 echo "trace rc=$?"
 python3 - "$out" <<'PY'
 import csv, glob, sys, json

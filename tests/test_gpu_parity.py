@@ -801,3 +801,34 @@ def test_a_queue_that_turns_up_after_an_empty_one_is_still_worked_off():
         engine.run_consensus_device(t, dev, out, strategy="relaxed")
         torch.cuda.synchronize()
         _assert_records_equal(engine.records_from_tensor(out), exp_b)
+
+
+@pytest.mark.parametrize("hits", [10, 50])
+def test_f64_identities_exact_milli_in_some_tasks_only(hits):
+    """f64 layouts (five columns, 24-byte side records): a wave task whose top-row identities are all exact milli-percent
+    values is ordered on the integers, any other one on the doubles — blocks of 64 queries of either kind side by side, and
+    tasks with a single inexact value (one more decimal, a value one ulp off a milli-percent value, 131.07 and up)."""
+    tax = synth.make_taxonomy(3000, 5)
+    t = _engine_tax(tax, "custom", H.CUSTOM_16S)
+    dh = synth.make_hits(tax, 64 * 24, 700 + hits, hits, p_unmatched=0.001)
+    h = dh.numpy()
+    rng = np.random.default_rng(hits)
+    pid = h["pident"].copy()
+    seg = h["seg_off"].astype(np.int64)
+    for task in range(24):
+        a, b = int(seg[64 * task]), int(seg[64 * (task + 1)])
+        kind = task % 4
+        if kind == 1:                                   # every value off the milli-percent grid
+            pid[a:b] = pid[a:b] + 0.0001234
+        elif kind == 2:                                 # one value of the task one ulp above a milli-percent value
+            i = a + int(rng.integers(0, b - a))
+            pid[i] = np.nextafter(pid[i], 200.0)
+        elif kind == 3:                                 # values the 17-bit key cannot hold
+            pid[a:b:7] = rng.choice(np.array([131.07, 131.071, 250.0]), len(pid[a:b:7]))
+    h["pident"] = pid
+    rows = t.engine_rows(h["tax_row"])
+    for strategy in ("relaxed", "cautious"):
+        exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S)
+        _assert_records_equal(_run_host(t, h, strategy), exp)
+        got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], strategy, packed="wide")
+        _assert_records_equal(got, exp)
