@@ -832,3 +832,23 @@ def test_f64_identities_exact_milli_in_some_tasks_only(hits):
         _assert_records_equal(_run_host(t, h, strategy), exp)
         got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], strategy, packed="wide")
         _assert_records_equal(got, exp)
+
+
+def test_hits_pack_on_the_device_writes_the_host_packs_words():
+    """blu_hits_pack / blu_hits_pack64 with device pointers (the kernels of pack_kernel.hip) against the host loop."""
+    import torch
+    tax = synth.make_taxonomy(4000, 29)
+    t = _engine_tax(tax, "bacteria")
+    dh = synth.make_hits(tax, 3000, 41, 20, device="cuda", p_unmatched=0.01)
+    dh.tax_row = t.engine_rows(dh.tax_row).contiguous()
+    h = {k: v.cpu().numpy() for k, v in dh.as_dict("milli").items()}
+    for layout, wide in (("packed", False), ("packed64", True)):
+        dev = dh.as_dict(layout, tax=t)[layout].cpu().numpy().view(np.uint32).reshape(-1, 6 if wide else 4)
+        host = engine.pack_records(t, h["tax_row"], None if wide else h["pident_milli"], h["align_len"], h["acc_rank"],
+                                   pident=dh.pident.cpu().numpy() if wide else None, wide=wide)
+        assert np.array_equal(dev, host), layout
+    bad = dh.as_dict("milli")
+    bad["pident_milli"] = bad["pident_milli"].clone()
+    bad["pident_milli"][17] = 131071
+    with pytest.raises(N.BluError, match="milli-percent"):
+        engine.pack_hits_device(t, bad)

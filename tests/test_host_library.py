@@ -201,3 +201,53 @@ def test_sharded_run_validates_the_offset_table_before_touching_a_device():
     assert run(bad, 50) == N.BLU_ERR_INVALID_ARG                      # not ascending
     assert run(seg, 50, (C.c_void_p * 2)(a.handle, a.handle)) == N.BLU_ERR_INVALID_ARG   # one handle twice
     assert run(seg, 50) == N.BLU_ERR_NO_DEVICE                        # well-formed: only now a device is needed
+
+
+def test_hits_pack_words_and_shape_hints():
+    """blu_hits_pack / blu_hits_pack64 on host arrays (no GPU): the four values of a hit side by side, and in the bits above
+    the 17-bit identity a hint that is a function of the row's rank sequence — the same for rows of one shape, different
+    for rows of different shapes (it is `shape id + 1`), 0 for an unmatched row; identities the 16-byte record cannot hold
+    are refused."""
+    tax = synth.make_taxonomy(3000, 23)
+    t = engine.Taxonomy(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, taxon="bacteria", device=-1)
+    rng = np.random.default_rng(1)
+    n = 5000
+    desc = rng.integers(0, tax.n, n).astype(np.int32)
+    desc[::97] = -1                                                    # unmatched
+    rows = t.engine_rows(desc)
+    pm = rng.integers(0, 131071, n).astype(np.uint32)
+    aln = rng.integers(-5, 3000, n).astype(np.int32)
+    acc = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    rec = engine.pack_records(t, rows, pm, aln, acc)
+    assert rec.shape == (n, 4)
+    assert np.array_equal(rec[:, 0], rows.view(np.uint32)) and np.array_equal(rec[:, 1] & 0x1FFFF, pm)
+    assert np.array_equal(rec[:, 2], aln.view(np.uint32)) and np.array_equal(rec[:, 3], acc)
+    hint = rec[:, 1] >> 17
+    shape_of = {}
+    for i in range(n):
+        if desc[i] < 0:
+            assert hint[i] == 0
+            continue
+        a, b = int(tax.lin_off[desc[i]]), int(tax.lin_off[desc[i] + 1])
+        key = tuple(tax.rank_names[r] for r in tax.lin_rank[a:b])
+        assert hint[i] != 0
+        assert shape_of.setdefault(key, int(hint[i])) == int(hint[i])
+    assert len(set(shape_of.values())) == len(shape_of) > 20           # one hint per shape
+    assert t.n_shapes >= len(shape_of) and max(shape_of.values()) <= t.n_shapes
+    # the wide records carry the f64 as it is
+    pid = pm.astype(np.float64) / 1000.0
+    pid[5] = np.nan; pid[6] = 1e308
+    wide = engine.pack_records(t, rows, None, aln, acc, pident=pid, wide=True)
+    assert wide.shape == (n, 6) and np.array_equal(wide[:, 1] >> 17, hint) and np.array_equal(wide[:, 1] & 0x1FFFF, np.zeros(n, np.uint32))
+    assert np.array_equal(wide[:, 4:6].copy().view(np.uint64).reshape(-1), pid.view(np.uint64))
+    # an exact milli-percent f64 column packs into the 16-byte records; anything else, or 131.071 and up, does not
+    ok = engine.pack_records(t, rows, None, aln, acc, pident=pm.astype(np.float64) / 1000.0)
+    assert np.array_equal(ok, rec)
+    for bad in (np.float64(97.0001), np.float64(131.071), np.float64(-1.0), np.nan):
+        p2 = pm.astype(np.float64) / 1000.0
+        p2[77] = bad
+        with pytest.raises(N.BluError, match="milli-percent"):
+            engine.pack_records(t, rows, None, aln, acc, pident=p2)
+    big = pm.copy(); big[3] = 131071
+    with pytest.raises(N.BluError, match="milli-percent"):
+        engine.pack_records(t, rows, big, aln, acc)
