@@ -502,20 +502,21 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
 
     // The offsets of a task are requested one task ahead (lane i: the row range of query q0 + i), so that their round
     // trip is never on the critical path and the next task's first chunks can be requested while this one finishes.
-    auto load_seg = [&](const uint64_t tk, uint64_t& o, uint64_t& e) {
+    // (The offsets are 64-bit in the ABI and below 2^32 by its n_hits limit: the kernel reads their low words only and does
+    // all row arithmetic in 32 bits.  A corrupt table with high words set reads as some other in-range table: clamped like
+    // any other, nothing faults.)
+    const uint32_t n_hits32 = (uint32_t)h.n_hits;
+    auto load_seg = [&](const uint64_t tk, uint32_t& o, uint32_t& e) {
         o = 0; e = 0;
         if (tk < n_tasks) {
             const uint64_t q = tk * WAVE + (uint32_t)lane;
             if (q < h.n_queries) {
-#ifdef BLU_SEG_NT
-                o = __builtin_nontemporal_load(h.seg_off + q); e = __builtin_nontemporal_load(h.seg_off + q + 1);
-#else
-                o = h.seg_off[q]; e = h.seg_off[q + 1];
-#endif
+                const uint32_t* lo32 = reinterpret_cast<const uint32_t*>(h.seg_off + q);
+                o = lo32[0]; e = lo32[2];
             }
         }
     };
-    uint64_t nx_off, nx_end;
+    uint32_t nx_off, nx_end;
     load_seg(wave, nx_off, nx_end);
     STAMP_DECL
 
@@ -523,8 +524,8 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         const uint64_t q0 = task * WAVE;
         const uint32_t nq = (uint32_t)((h.n_queries - q0) < WAVE ? (h.n_queries - q0) : WAVE);
         // lane i holds the row range of query q0 + i
-        uint64_t my_off = nx_off, my_end = nx_end;
-        if (my_end > h.n_hits) my_end = h.n_hits;   // defend the column reads against a corrupt offset table
+        uint32_t my_off = nx_off, my_end = nx_end;
+        if (my_end > n_hits32) my_end = n_hits32;   // defend the column reads against a corrupt offset table
         if (my_off > my_end) my_off = my_end;
         const uint64_t next_task = task + n_waves;
         load_seg(next_task, nx_off, nx_end);        // consumed after this task's phase 1 (prefetch decision) and by the next iteration
@@ -536,7 +537,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         // per-lane (= per-query) results of phase 2a
         // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
         const uint64_t q = q0 + (uint32_t)lane;
-        const uint32_t row0 = (uint32_t)my_off;
+        const uint32_t row0 = my_off;
         // (r_len: lineage length of the reference row in bits 0..7, the shape hint of its side record above — packed layout,
         // 0 = none: the shape then comes from the row)
         uint32_t mode = 3, r_len = 0, r_row = 0, r_pos = 0, r_hdr = 0, minlen = 0, d = 0, rec_kind = 0, g_lo = 0, g_hi = 0;
@@ -551,13 +552,13 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         // offsets (< 2^31 also for the 8-byte column), no 64-bit VALU address math, and the hardware range check
         // returns 0 for lanes past the end of the table or of the span.  A query that does not lie inside the span
         // (a giant segment earlier in the task, or an offset table that is not ascending) goes to the worklist.
-        const uint64_t task_start = rl_u64(my_off, 0);
-        const uint64_t rem = (h.n_hits - task_start) < TASK_SPAN ? (h.n_hits - task_start) : TASK_SPAN;
+        const uint32_t task_start = (uint32_t)rl((int)my_off, 0);
+        const uint64_t rem = (uint64_t)(n_hits32 - task_start) < TASK_SPAN ? (uint64_t)(n_hits32 - task_start) : TASK_SPAN;
         const uint32_t rem4 = (uint32_t)(rem * 4), rem8 = (uint32_t)(rem * 8);
         const auto rs_bs = __builtin_amdgcn_make_buffer_rsrc((void*)(h.bitscore + task_start), 0, rem4, 0x00020000);
         // (packed layout: rs_tax is the descriptor of the 16-byte records; the other three column descriptors are unused)
-        const auto rs_tax = PACKED ? __builtin_amdgcn_make_buffer_rsrc((void*)(h.packed + 4 * task_start), 0, (uint32_t)(rem * 16), 0x00020000)
-                            : WIDE ? __builtin_amdgcn_make_buffer_rsrc((void*)(h.packed64 + 6 * task_start), 0, (uint32_t)(rem * 24), 0x00020000)
+        const auto rs_tax = PACKED ? __builtin_amdgcn_make_buffer_rsrc((void*)(h.packed + 4ull * task_start), 0, (uint32_t)(rem * 16), 0x00020000)
+                            : WIDE ? __builtin_amdgcn_make_buffer_rsrc((void*)(h.packed64 + 6ull * task_start), 0, (uint32_t)(rem * 24), 0x00020000)
                                    : __builtin_amdgcn_make_buffer_rsrc((void*)(h.tax_row + task_start), 0, rem4, 0x00020000);
         const auto rs_aln = __builtin_amdgcn_make_buffer_rsrc((void*)(h.align_len + task_start), 0, rem4, 0x00020000);
         const auto rs_acc = __builtin_amdgcn_make_buffer_rsrc((void*)(h.acc_rank + task_start), 0, rem4, 0x00020000);
@@ -566,23 +567,23 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         // per-query {first row, row count} of the task, relative to task_start; count 0 also for segments > 64 rows
         // (those go to the worklist in phase 2a) so that phase 1 simply finds no top row in them
         {
-            const uint64_t nrows = my_end - my_off;
-            in_span = my_off >= task_start && (my_end - task_start) <= TASK_SPAN;
-            L.seg[lane] = make_uint2((uint32_t)(my_off - task_start), (nrows <= MAX_TASK_SEG && in_span) ? (uint32_t)nrows : 0u);
+            const uint32_t nrows = my_end - my_off;
+            in_span = my_off >= task_start && (my_end - task_start) <= (uint32_t)TASK_SPAN;
+            L.seg[lane] = make_uint2(my_off - task_start, (nrows <= MAX_TASK_SEG && in_span) ? nrows : 0u);
         }
         // A task whose queries lie back to back in ascending order, none longer than SHORT_SEG rows, can take its
         // bit-scores through the ring (lane i: does query i start where query i - 1 ends?)
-        const uint32_t task_rows = (uint32_t)(((uint32_t)lane < nq ? my_end : 0ull) - ((uint32_t)lane < nq ? task_start : 0ull));   // (meaningful in lane nq - 1)
+        const uint32_t task_rows = ((uint32_t)lane < nq ? my_end : 0u) - ((uint32_t)lane < nq ? task_start : 0u);   // (meaningful in lane nq - 1)
         bool contiguous, all_short;
         {
-            const uint32_t rel_end = (uint32_t)(my_end - task_start), rel_off = (uint32_t)(my_off - task_start);
+            const uint32_t rel_end = my_end - task_start, rel_off = my_off - task_start;
             const uint32_t prev_end = (uint32_t)__shfl_up((int)rel_end, 1);
             const bool ok = in_span && (lane == 0 || rel_off == prev_end);
             contiguous = __ballot((uint32_t)lane < nq && !ok) == 0ull;
             all_short = __ballot((uint32_t)lane < nq && (my_end - my_off) > SHORT_SEG) == 0ull;
         }
         const uint32_t task_nrows = (uint32_t)rl((int)task_rows, (int)nq - 1);   // rows of the whole task (contiguous tasks)
-        const uint64_t vbase = task_start + mis;                                 // v of the task's first row
+        const uint64_t vbase = (uint64_t)task_start + mis;                       // v of the task's first row
         // Segments over SHORT_SEG rows are not read through the ring (long pass / worklist kernel): the whole chunks inside
         // them are left out of the ring's numbering, so that a task of mixed lengths streams only what its steps read.
         // Lane i (= query i): chunks left out before it (sk_before), where its own left-out chunks begin in the ring's
@@ -607,7 +608,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             ev_v = c_first - sk_before;
             ev_cum = incl;
         }
-        const uint32_t seg_x = (uint32_t)(my_off - task_start) - 256u * sk_before;   // lane i: first row of query i in the ring's numbering, relative to the task
+        const uint32_t seg_x = (my_off - task_start) - 256u * sk_before;   // lane i: first row of query i in the ring's numbering, relative to the task
         L.vx[lane] = seg_x;
         auto ring_phys = [&](const uint32_t vc) {                               // chunk vc of the ring's numbering -> chunk of the column
             const uint64_t m = __ballot(ev_on && ev_v <= vc);
@@ -1544,26 +1545,25 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         STAMP(1)   // phase 1
         // Last round of the task (nothing left pending): the ring is free, so the first chunks of the NEXT task are
         // requested now and travel while this task finishes (its offsets were requested when this task began).
-        const bool last_round = __ballot(pend && (my_end - my_off) != 0ull && (my_end - my_off) <= MAX_TASK_SEG && in_span && (L.meta[lane] & META_SLOW)) == 0ull;
+        const bool last_round = __ballot(pend && (my_end - my_off) != 0u && (my_end - my_off) <= MAX_TASK_SEG && in_span && (L.meta[lane] & META_SLOW)) == 0ull;
         uint32_t nxt_c0 = 0, nxt_lim = 0;
         if (RING && last_round && next_task < n_tasks) {
             // (opaque to the optimizer: otherwise what follows is hoisted out of the rounds loop to right behind the load and
             // the task would start by waiting for the next task's offsets)
-            uint32_t o_lo = (uint32_t)nx_off, o_hi = (uint32_t)(nx_off >> 32), e_lo = (uint32_t)nx_end, e_hi = (uint32_t)(nx_end >> 32);
-            asm volatile("" : "+v"(o_lo), "+v"(o_hi), "+v"(e_lo), "+v"(e_hi));
-            uint64_t n_off = ((uint64_t)o_hi << 32) | o_lo, n_end = ((uint64_t)e_hi << 32) | e_lo;
-            if (n_end > h.n_hits) n_end = h.n_hits;
+            uint32_t n_off = nx_off, n_end = nx_end;
+            asm volatile("" : "+v"(n_off), "+v"(n_end));
+            if (n_end > n_hits32) n_end = n_hits32;
             if (n_off > n_end) n_off = n_end;
             const uint64_t nq0 = next_task * WAVE;
             const uint32_t nqn = (uint32_t)((h.n_queries - nq0) < WAVE ? (h.n_queries - nq0) : WAVE);
-            const uint64_t n_start = rl_u64(n_off, 0);
-            const bool n_span = n_off >= n_start && (n_end - n_start) <= TASK_SPAN;
-            const uint32_t rel_end = (uint32_t)(n_end - n_start), rel_off = (uint32_t)(n_off - n_start);
+            const uint32_t n_start = (uint32_t)rl((int)n_off, 0);
+            const bool n_span = n_off >= n_start && (n_end - n_start) <= (uint32_t)TASK_SPAN;
+            const uint32_t rel_end = n_end - n_start, rel_off = n_off - n_start;
             const uint32_t prev_end = (uint32_t)__shfl_up((int)rel_end, 1);
             const bool ok = n_span && (n_end - n_off) <= SHORT_SEG && (lane == 0 || rel_off == prev_end);
             const uint32_t n_rows = (uint32_t)rl((int)rel_end, (int)nqn - 1);
             if (__ballot((uint32_t)lane < nqn && !ok) == 0ull && n_rows != 0u) {
-                const uint64_t vb = n_start + mis;
+                const uint64_t vb = (uint64_t)n_start + mis;
                 nxt_c0 = (uint32_t)(vb >> 8);
                 const uint32_t cend = (uint32_t)((vb + n_rows - 1u) >> 8) + 1u;
                 nxt_lim = cend < nxt_c0 + RING_CHUNKS ? cend : nxt_c0 + RING_CHUNKS;
@@ -1589,7 +1589,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         // whose group is shorter re-reads its last entry (every update below is idempotent), so there is no divergent
         // control flow and the LDS reads of consecutive entries overlap.
         {
-            const uint64_t nrows = my_end - my_off;
+            const uint32_t nrows = my_end - my_off;
             const uint32_t m = L.meta[lane];
             const bool listed = pend && nrows != 0 && nrows <= MAX_TASK_SEG && in_span && !(m & (META_SLOW | META_DENSE)) && !BLU_X_SKIP_2A;
             const uint32_t first = listed ? (m & 0xFFFFu) : 0u, k = listed ? ((m >> 16) & 0x3FFu) : 0u;
