@@ -113,6 +113,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            for (auto& set : tax->ws_stage_bytes) for (size_t b : set) free_b += b;   // (what the handle holds already is there to be used)
             const size_t budget = free_b / 5 * 2 / row_bytes;          // two buffer sets within 80 % of what is free
             if (budget < chunk_rows) chunk_rows = budget;
         }
@@ -154,19 +155,31 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     };
     {
         const size_t pad = 64;  // keeps zero-length columns allocatable
+        // the staging buffers live with the handle (grow-only): a caller that runs table after table pays for them once
+        auto stage = [&](int k, int slot, size_t bytes, void** p) -> hipError_t {
+            if (tax->ws_stage_bytes[k][slot] < bytes) {
+                if (tax->ws_stage[k][slot]) (void)hipFree(tax->ws_stage[k][slot]);
+                tax->ws_stage[k][slot] = nullptr; tax->ws_stage_bytes[k][slot] = 0;
+                const hipError_t e = hipMalloc(&tax->ws_stage[k][slot], bytes);
+                if (e != hipSuccess) return e;
+                tax->ws_stage_bytes[k][slot] = bytes;
+            }
+            *p = tax->ws_stage[k][slot];
+            return hipSuccess;
+        };
         for (int k = 0; k < n_sets; ++k) {
             Set& st = sets[k];
-            HIP_TRY(hipMalloc(&st.bs, max_rows * 4 + pad));
-            if (packed) HIP_TRY(hipMalloc(&st.pid, max_rows * 16 + pad));   // the 16-byte records
-            else if (wide) HIP_TRY(hipMalloc(&st.pid, max_rows * 24 + pad));   // the 24-byte records
+            HIP_TRY(stage(k, 0, max_rows * 4 + pad, &st.bs));
+            if (packed) HIP_TRY(stage(k, 1, max_rows * 16 + pad, &st.pid));   // the 16-byte records
+            else if (wide) HIP_TRY(stage(k, 1, max_rows * 24 + pad, &st.pid));   // the 24-byte records
             else {
-                HIP_TRY(hipMalloc(&st.tax, max_rows * 4 + pad));
-                HIP_TRY(hipMalloc(&st.pid, max_rows * (milli ? 4 : 8) + pad));
-                HIP_TRY(hipMalloc(&st.aln, max_rows * 4 + pad));
-                HIP_TRY(hipMalloc(&st.acc, max_rows * 4 + pad));
+                HIP_TRY(stage(k, 2, max_rows * 4 + pad, &st.tax));
+                HIP_TRY(stage(k, 1, max_rows * (milli ? 4 : 8) + pad, &st.pid));
+                HIP_TRY(stage(k, 3, max_rows * 4 + pad, &st.aln));
+                HIP_TRY(stage(k, 4, max_rows * 4 + pad, &st.acc));
             }
-            HIP_TRY(hipMalloc(&st.seg, (max_q + 1) * 8));
-            HIP_TRY(hipMalloc(&st.out, std::max<size_t>(max_q, 1) * sizeof(blu_result)));
+            HIP_TRY(stage(k, 5, (max_q + 1) * 8, &st.seg));
+            HIP_TRY(stage(k, 6, std::max<size_t>(max_q, 1) * sizeof(blu_result), &st.out));
             if (n_chunks > 1) HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
             else st.s = (hipStream_t)params->stream;
         }
@@ -214,7 +227,6 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
 done:
     for (Set& st : sets) {
         if (st.busy && st.s) (void)hipStreamSynchronize(st.s);
-        for (void* p : {st.bs, st.tax, st.pid, st.aln, st.acc, st.seg, st.out}) if (p) (void)hipFree(p);
         if (n_chunks > 1 && st.s) (void)hipStreamDestroy(st.s);
     }
     if (kernels_done) (void)hipEventDestroy(kernels_done);

@@ -147,4 +147,9 @@ struct blu_taxonomy {
     mutable uint64_t ws_calls = 0;
     mutable const void* ws_kind_key_ptr = nullptr;   // the table the remembered kind belongs to: its offsets pointer and query count
     mutable uint64_t ws_kind_key_n = 0;
+    // Staging buffers of the host-pointer path of blu_consensus_run (two sets: a table staged in chunks is double-buffered),
+    // kept with the handle and grown on demand instead of seven hipMalloc / hipFree pairs per call; [k][slot]: slot 0 bit-scores,
+    // 1 side values (records, or the perc_identity column), 2 tax rows, 3 align_length, 4 accession ranks, 5 offsets, 6 records out
+    mutable void* ws_stage[2][7] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
+    mutable size_t ws_stage_bytes[2][7] = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0}};
 };

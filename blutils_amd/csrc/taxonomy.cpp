@@ -467,6 +467,7 @@ void blu_taxonomy_destroy(blu_taxonomy* tax) {
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
         if (tax->ws_count) (void)hipFree(tax->ws_count);
         if (tax->ws_kind_host) (void)hipHostFree(tax->ws_kind_host);
+        for (auto& set : tax->ws_stage) for (void* p : set) if (p) (void)hipFree(p);
     }
     delete tax;
 }
