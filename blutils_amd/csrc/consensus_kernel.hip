@@ -532,6 +532,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         asm volatile("" ::: "memory");              // (keeps these loads in front of the ring requests below: the counted waits rely on it)
         uint32_t fill = 0;   // wave-uniform: entries used in the LDS list
         bool keyed = false;  // wave-uniform: the list of this round holds comparison-ready entries (see gather_list)
+        bool keyed_bad = false;   // wave-uniform: some comparison-ready entry of the round is a row without a (well-formed) lineage
         uint32_t scan_rpl = 16;   // wave-uniform: rows per lane of this round's ring steps (16 or 32: the descriptor format)
         uint32_t fill_ring = 0;   // wave-uniform: list entries of this round that came from ring steps (lane descriptors until the gather)
         // per-lane (= per-query) results of phase 2a
@@ -1411,12 +1412,14 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 }
             }
             keyed = __ballot(ovf) == 0ull && fill == fill_ring;   // (entries appended by the long pass are plain records)
+            bool any_bad = false;
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
                 const uint32_t idx = (uint32_t)u * WAVE + (uint32_t)lane;
                 if (idx < fill_ring) {
                     if (keyed) {
                         const uint32_t len = umin(g[u].x >> BLU_ROW_BITS, t.max_depth);
+                        any_bad |= len == 0u || (g[u].x & ROW_MASK) >= t.n_tax;
                         const uint32_t hint = (PID32 ? g[u].y : ghint[u]) >> KEY_PID_BITS;   // (the layouts with side records; else 0)
                         L.rec[idx] = make_uint4((g[u].x & ROW_MASK) | ((hint >> 8) << BLU_ROW_BITS),
                                                 (len << KEYED_LEN_SHIFT) | (gk[u] << KEYED_PID_SHIFT) | (hint & 0xFFu), g[u].z ^ 0x80000000u, g[u].w);
@@ -1425,6 +1428,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     if (!PID32) L.p1[idx] = ghi[u];
                 }
             }
+            keyed_bad = __ballot(any_bad) != 0ull;   // (a round without one — nine in ten on C3 — skips the error tests of phase 2a)
         };
         // Phase 1 and phase 2a run in ROUNDS: a round compacts the top rows of as many pending queries as the LDS list holds
         // (the steps that do not fit are marked and come again), phase 2a reduces them, the list is reused.  With small
@@ -1610,13 +1614,15 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 l_keyed = 1u;
                 uint64_t BK = 0;                         // best (length, perc_identity, align_length) so far
                 uint32_t kmin = 0xFFFFFFFFu, pmax = 0;
-                uint32_t l_x = 0, l_y = 0;               // .x / .y of the entry taken last: its position and shape hint come out after the loop
-                auto step = [&](const uint4 x, const uint32_t xpos, const bool is_first) {
+                uint32_t l_idx = first;                  // list slot of the entry taken last: its position, row and shape hint are read after the loop
+                auto step = [&](const auto check_c, const uint4 x, const uint32_t xidx, const bool is_first) {
                     const uint32_t pos = x.x & ROW_MASK;
-                    const bool unmatched = pos >= t.n_tax, bad = x.y < (1u << KEYED_LEN_SHIFT);   // (lineage length 0)
-                    const bool first_err = (err == 0) & (unmatched | bad);
-                    err = first_err ? (unmatched ? (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID : (uint32_t)BLU_ST_ERR_BAD_LINEAGE) : err;
-                    err_pos = first_err ? xpos : err_pos;
+                    if constexpr (decltype(check_c)::value) {   // (only in a round that holds a row without a lineage: parse errors in file order)
+                        const bool unmatched = pos >= t.n_tax, bad = x.y < (1u << KEYED_LEN_SHIFT);   // (lineage length 0)
+                        const bool first_err = (err == 0) & (unmatched | bad);
+                        err = first_err ? (unmatched ? (uint32_t)BLU_ST_ERR_UNMATCHED_TAXID : (uint32_t)BLU_ST_ERR_BAD_LINEAGE) : err;
+                        err_pos = first_err ? (uint32_t)L.pq[xidx] : err_pos;
+                    }
                     kmin = umin(kmin, x.y);
                     lo = umin(lo, pos);
                     hi = pos > hi ? pos : hi;
@@ -1628,23 +1634,25 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     const bool take = is_first | (STRAT == BLU_RELAXED ? (gt | eq) : !(gt | eq));
                     BK = take ? K : BK;
                     b_acc = take ? x.w : b_acc;
-                    l_x = take ? x.x : l_x;
-                    l_y = take ? x.y : l_y;
-                    l_pos = take ? xpos : l_pos;
+                    l_idx = take ? xidx : l_idx;
                 };
                 // four entries per trip, their LDS reads issued together: one read latency per four entries
-                for (uint32_t e = 0; e < kmax; e += 4) {
-                    uint4 x[4];
-                    uint32_t xp[4];
+                auto reduce = [&](const auto check_c) {
+                    for (uint32_t e = 0; e < kmax; e += 4) {
+                        uint4 x[4];
+                        uint32_t xi[4];
 #pragma unroll
-                    for (uint32_t j = 0; j < 4; ++j) {
-                        const uint32_t idx = first + (e + j < k ? e + j : last_e);
-                        x[j] = L.rec[idx];
-                        xp[j] = L.pq[idx];
+                        for (uint32_t j = 0; j < 4; ++j) {
+                            xi[j] = first + (e + j < k ? e + j : last_e);
+                            x[j] = L.rec[xi[j]];
+                        }
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) step(check_c, x[j], xi[j], e == 0 && j == 0);
                     }
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; ++j) step(x[j], xp[j], e == 0 && j == 0);
-                }
+                };
+                if (keyed_bad) reduce(std::true_type()); else reduce(std::false_type());
+                const uint32_t l_x = L.rec[l_idx].x, l_y = L.rec[l_idx].y;
+                l_pos = L.pq[l_idx];
                 const uint32_t k1 = (uint32_t)(BK >> 32);
                 b_len = k1 >> KEYED_LEN_SHIFT;
                 l_minlen = kmin >> KEYED_LEN_SHIFT;
