@@ -1887,7 +1887,9 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     auto level = [&](uint32_t j, uint32_t packed) {
                         if (j < len_ref) {
                             const uint32_t cid = packed & ((1u << BLU_PACK_CUT_BITS) - 1u);
-                            const double cj = cut_in_lds ? s_cut[cid] : t.cutvals[cid];
+                            double cj = s_cut[cut_in_lds ? cid : 0u];
+                            asm volatile("" : "+v"(cj));     // (an LDS read of its own: see ranks_of)
+                            if (!cut_in_lds) cj = t.cutvals[cid];
                             if (mar_level == BLU_NONE_U8 && !(ident > cj)) mar_level = j;   // skip_while(identity > cutoff)
                             if (ident >= cj) {                                             // filter(identity >= cutoff)
                                 F |= 1ull << j;
@@ -1911,7 +1913,11 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 }
                 // {canonical rank code, max-allowed-rank code} of level j (the lane's own words: written and read by the same lane)
                 auto ranks_of = [&](const uint32_t j, uint32_t& rank, uint32_t& mar) {
-                    const uint32_t v = j < 16u ? stage[j] : (by_k ? lvl[j] : codes[j]);
+                    // (two statements, not one conditional expression: that made hipcc merge the LDS and the global address into one
+                    // generic pointer — flat loads, 64-bit address arithmetic per lookup and a spilled pointer)
+                    uint32_t v = stage[j < 16u ? j : 15u];
+                    asm volatile("" : "+v"(v));          // (the LDS read is a read of its own, whatever follows)
+                    if (j >= 16u) v = by_k ? lvl[j] : codes[j];
                     if (by_k) { rank = (v >> BLU_LVL_RANK_SHIFT) & BLU_PACK_CODE_MASK; mar = ((v >> BLU_LVL_NEVER_SHIFT) & 1u) ? (uint32_t)BLU_MAR_NEVER_EQUAL : rank; }
                     else { rank = packed_rank(v); mar = packed_mar(v); }
                 };
