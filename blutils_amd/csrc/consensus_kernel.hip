@@ -222,6 +222,16 @@ __device__ __forceinline__ void store_status(blu_result* out, uint64_t q, uint32
 // parser yields for a value printed with at most three decimals (IEEE f64 division; this file is built without
 // fast-math)
 __device__ __forceinline__ double milli_to_f64(uint32_t k) { return (double)k / 1000.0; }
+// The same for k < 2^17 (every value the packed layouts and the keyed f64 rounds hold) without the division: with y = fl(1/1000),
+// q = fl(k y), r = fma(-q, 1000, k) (exact) and fma(r, y, q) is the correctly rounded k / 1000 for EVERY k in [0, 131072) —
+// checked exhaustively against the exact quotient on the host (rational arithmetic) and on the device against the division
+// (tests/test_gpu_milli_exact.py); three f64 operations instead of the dozen of an IEEE division.
+__device__ __forceinline__ double milli17_to_f64(uint32_t k) {
+    const double x = (double)k, y = 0.001;
+    const double q = x * y;
+    const double r = __builtin_fma(-q, 1000.0, x);
+    return __builtin_fma(r, y, q);
+}
 
 // packed level word of a lineage row -> the ABI's 16-bit rank codes
 __device__ __forceinline__ uint32_t packed_rank(uint32_t p) { return (p >> BLU_PACK_CUT_BITS) & BLU_PACK_CODE_MASK; }
@@ -1406,7 +1416,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     const double p = __hiloint2double((int)ghi[u], (int)g[u].y);
                     const bool in_range = p >= 0.0 && p < 131.0705;
                     const uint32_t k = in_range ? (uint32_t)(p * 1000.0 + 0.5) : 0u;
-                    const double back = milli_to_f64(k);
+                    const double back = milli17_to_f64(k);   // (k < 2^17: in_range)
                     gk[u] = k;
                     ovf |= valid && !(in_range && __double2hiint(back) == (int)ghi[u] && __double2loint(back) == (int)g[u].y && k < BLU_KTHR_NEVER);
                 }
@@ -1659,7 +1669,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 l_row = l_x & ROW_MASK;
                 l_hint = ((l_x >> BLU_ROW_BITS) << 8) | (l_y & 0xFFu);
                 if constexpr (PID32) { b_pid = (k1 >> KEYED_PID_SHIFT) & PM_MASK; l_maxpid = pmax; }
-                else { b_pid = milli_to_f64((k1 >> KEYED_PID_SHIFT) & PM_MASK); l_maxpid = milli_to_f64(pmax); }   // (the doubles they came from, bit for bit)
+                else { b_pid = milli17_to_f64((k1 >> KEYED_PID_SHIFT) & PM_MASK); l_maxpid = milli17_to_f64(pmax); }   // (the doubles they came from, bit for bit)
             } else {
                 for (uint32_t e = 0; e < kmax; ++e) {
                     const uint4 x = nx_rec;              // {row id, pident, align_len, accession rank}
@@ -1812,7 +1822,9 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 const uint32_t* lvl = t.kthr + (uint64_t)shape * t.cstride;
                 const uint4* lvl4 = reinterpret_cast<const uint4*>(lvl);
                 const uint32_t b = single ? len_ref : (agree ? minlen - 1 : d - 1);
-                const double ident = pid_f64<PID32>((single | agree) ? r_pid : max_pid);   // the one f64 the cutoff tests need
+                double ident;   // the one f64 the cutoff tests need / the record carries
+                if constexpr (PACKED) ident = milli17_to_f64(((single | agree) ? r_pid : max_pid) & PM_MASK);   // (17-bit identities: no division)
+                else ident = pid_f64<PID32>((single | agree) ? r_pid : max_pid);
                 // Milli-percent layouts: `fl(k / 1000) >= c` is monotone in k, so every cutoff c has a smallest k that passes
                 // it (taxonomy.cpp: kthr, 17 bits, + 1 bit "fl(k / 1000) == c", i.e. `>` needs one more) and the level tests
                 // are integer compares of the query's milli-percent identity — no cutoff value is read.  Identities of

@@ -251,3 +251,15 @@ def test_hits_pack_words_and_shape_hints():
     big = pm.copy(); big[3] = 131071
     with pytest.raises(N.BluError, match="milli-percent"):
         engine.pack_records(t, rows, big, aln, acc)
+
+
+def test_division_free_milli_percent_conversion_is_exact_for_17_bit_values():
+    """consensus_kernel.hip `milli17_to_f64`: with y = fl(1/1000), q = fl(k y), r = fma(-q, 1000, k), the value fma(r, y, q) is
+    the correctly rounded k / 1000 for every k below 2^17 — here in exact rational arithmetic (a Fraction converts to the
+    nearest double), on the device in tests/test_gpu_milli_exact.py."""
+    from fractions import Fraction
+    y = Fraction(0.001)
+    for k in range(0, 1 << 17):
+        q = float(Fraction(k) * y)
+        r = float(Fraction(k) - Fraction(q) * 1000)
+        assert float(Fraction(q) + Fraction(r) * y) == k / 1000.0, k
