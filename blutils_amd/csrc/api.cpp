@@ -82,8 +82,9 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         // grows only when a larger table than any before arrives (first call): not graph-capturable
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
         if (!tax->ws_count) {
-            if (hipMalloc((void**)&tax->ws_count, 256) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return BLU_ERR_ALLOC; }
-            if (hipMemset(tax->ws_count, 0, 256) != hipSuccess) { set_error("hipMemset(workspace) failed"); return BLU_ERR_HIP; }
+            // (counters of the run, then the 64 worklist queues' counters, one memory line each: consensus_kernel.hip WL_BASE / WL_STRIDE)
+            if (hipMalloc((void**)&tax->ws_count, 16384) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return BLU_ERR_ALLOC; }
+            if (hipMemset(tax->ws_count, 0, 16384) != hipSuccess) { set_error("hipMemset(workspace) failed"); return BLU_ERR_HIP; }
             // (without the pinned word every call classifies its table on the device: slower by two kernel boundaries, not wrong)
             if (hipHostMalloc((void**)&tax->ws_kind_host, 64, hipHostMallocDefault) == hipSuccess) {
                 tax->ws_kind_host[0] = 0; tax->ws_kind_host[1] = 0xFFFFFFFFu;
@@ -92,7 +93,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         }
         tax->ws_worklist = nullptr;
         tax->ws_capacity = 0;
-        if (hipMalloc((void**)&tax->ws_worklist, (hits->n_queries + 64) * sizeof(uint32_t)) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return BLU_ERR_ALLOC; }
+        if (hipMalloc((void**)&tax->ws_worklist, (hits->n_queries + 8192) * sizeof(uint32_t)) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return BLU_ERR_ALLOC; }
         tax->ws_capacity = hits->n_queries;
     }
     if (hits->on_device) {

@@ -49,6 +49,9 @@ namespace blu {
 // FLAGS="-DBLU_EXPERIMENTS -DBLU_X_...=true"): they produce WRONG records.  The product build leaves them all false and
 // the compiler drops the tests.
 #ifndef BLU_EXPERIMENTS
+#define BLU_X_SKIP_PUSH false
+#define BLU_X_SKIP_STORES false
+#define BLU_X_SKIP_P1 false
 #define BLU_X_SKIP_2A false
 #define BLU_X_SKIP_2C false
 #define BLU_X_SKIP_RUNLEN false
@@ -58,6 +61,15 @@ namespace blu {
 #else
 #ifndef BLU_X_SCAN_MIN
 #define BLU_X_SCAN_MIN false
+#endif
+#ifndef BLU_X_SKIP_P1
+#define BLU_X_SKIP_P1 false
+#endif
+#ifndef BLU_X_SKIP_PUSH
+#define BLU_X_SKIP_PUSH false
+#endif
+#ifndef BLU_X_SKIP_STORES
+#define BLU_X_SKIP_STORES false
 #endif
 #ifndef BLU_X_SKIP_2A
 #define BLU_X_SKIP_2A false
@@ -98,7 +110,9 @@ __device__ uint32_t g_stamps[8192 * 16];   // [wave][16]: cycles per phase, summ
 #ifndef BLOCK_N
 #define BLOCK_N 1024  // the kernel without the ring: 16 waves per CU (four per SIMD, 128 VGPRs)
 #endif
+#ifndef BLU_N_WAVES_PER_SIMD
 #define BLU_N_WAVES_PER_SIMD 4
+#endif
 #ifndef LIST_CAP
 #define LIST_CAP 208       // top-group entries per wave task (64 queries; mean ~183, sigma ~18 at geometric(0.35) groups)
 #endif
@@ -136,10 +150,22 @@ __device__ __forceinline__ int wave_min_i32(int x) {
     ROW_REDUCE(x, imin)
     return imin(imin(rl(x, 0), rl(x, 16)), imin(rl(x, 32), rl(x, 48)));
 }
+#ifndef BLU_FLAT_ALWAYS
+#define BLU_FLAT_ALWAYS 0   // experiment: every round of the kernel without the ring takes the flat pass
+#endif
 #ifndef BLU_FLAT_PASS
 #define BLU_FLAT_PASS 1
 #endif
-#define FLAT_SEG 256u            // longest segment the flat pass takes (64 quads: one step); longer ones take the long pass
+#ifndef FLAT_ROWS
+#define FLAT_ROWS 8u             // rows per lane of a flat step (two 16-byte loads)
+#endif
+#define FLAT_SEG (64u * FLAT_ROWS)   // longest segment the flat pass takes (64 lane units)
+#ifndef FLAT_STEPS
+#define FLAT_STEPS 8u            // steps (of 64 units) a flat round takes at most: two registers per step and lane
+#endif
+#ifndef FLAT_DEPTH
+#define FLAT_DEPTH 4u            // steps whose bit-scores are in flight together
+#endif
 __device__ __forceinline__ int iadd(int a, int b) { return a + b; }
 __device__ __forceinline__ int wave_sum_u32(uint32_t v) {
     int x = (int)v;
@@ -148,6 +174,36 @@ __device__ __forceinline__ int wave_sum_u32(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return (uint32_t)wave_max_i32((int)(v ^ 0x80000000u)) ^ 0x80000000u; }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return (uint32_t)wave_min_i32((int)(v ^ 0x80000000u)) ^ 0x80000000u; }
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    uint32_t incl = v;
+    incl += (uint32_t)dpp<0x111>((int)incl);
+    incl += (uint32_t)dpp<0x112>((int)incl);
+    incl += (uint32_t)dpp<0x114>((int)incl);
+    incl += (uint32_t)dpp<0x118>((int)incl);
+    const uint32_t t0 = (uint32_t)rl((int)incl, 15), t1 = (uint32_t)rl((int)incl, 31), t2 = (uint32_t)rl((int)incl, 47);
+    const uint32_t r16 = (uint32_t)lane_id() >> 4;
+    return incl + (r16 == 0 ? 0u : (r16 == 1 ? t0 : (r16 == 2 ? t0 + t1 : t0 + t1 + t2)));
+}
+// The worklist is WL_QUEUES queues, each with its own counter on a memory line of its own: a task appends to queue
+// (task % WL_QUEUES).  (One counter for all: the 15 600 tasks of C5 each append once per kernel, and 4096 waves adding to ONE
+// address get about one atomic per 11 ns out of the memory side — 175 us of a 260-us kernel went into waiting for that
+// counter, whatever the rest of the kernel did.)  Queue s: entries worklist[s * cap ..], cap = the queries of the tasks that
+// append to it; live counter work_count[WL_BASE + s * WL_STRIDE], the length published for the worklist kernel one word on.
+#define WL_QUEUES 64u
+#define WL_BASE 64u
+#define WL_STRIDE 32u
+__device__ __forceinline__ uint32_t wl_capacity(uint64_t n_queries) {
+    const uint64_t n_tasks = (n_queries + WAVE - 1) / WAVE;
+    return (uint32_t)((n_tasks + WL_QUEUES - 1) / WL_QUEUES) * WAVE;
+}
+// entry wi of the queues taken one after the other (incl: inclusive prefix sums of their lengths, lane = queue)
+__device__ __forceinline__ uint32_t wl_entry(const uint32_t* __restrict__ worklist, const uint32_t cap, const uint32_t incl, const uint32_t wi) {
+    const uint32_t sub = (uint32_t)__builtin_popcountll(__ballot(incl <= wi));
+    const uint32_t before = sub ? (uint32_t)rl((int)incl, (int)sub - 1) : 0u;
+    return __hip_atomic_load(worklist + (uint64_t)sub * cap + (wi - before), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
@@ -476,6 +532,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     WaveLds<!PID32, RING>& L = s_lds[wib];
     const uint64_t n_tasks = (h.n_queries + WAVE - 1) / WAVE;
+    const uint32_t wl_cap = wl_capacity(h.n_queries);
     const uint64_t wave = (uint64_t)blockIdx.x * WAVES_T + wib;
     const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_T;
 
@@ -533,6 +590,9 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     for (uint64_t task = wave; task < n_tasks; task += n_waves) {
         const uint64_t q0 = task * WAVE;
         const uint32_t nq = (uint32_t)((h.n_queries - q0) < WAVE ? (h.n_queries - q0) : WAVE);
+        // the worklist queue this task appends to
+        uint32_t* const wl_cnt = work_count + WL_BASE + ((uint32_t)task & (WL_QUEUES - 1u)) * WL_STRIDE;
+        uint32_t* const wl_q = worklist + (uint64_t)((uint32_t)task & (WL_QUEUES - 1u)) * wl_cap;
         // lane i holds the row range of query q0 + i
         uint32_t my_off = nx_off, my_end = nx_end;
         if (my_end > n_hits32) my_end = n_hits32;   // defend the column reads against a corrupt offset table
@@ -932,18 +992,27 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         // ---------------- phase 1, FLAT pass (kernel without the ring): lanes dealt to the queries by need ----------------
         // A task of mixed segment lengths (Zipf-like hit counts) wastes most lanes of the passes above: every streamed query
         // pays the lanes of the widest one, and each longer one takes half a step of its own.  Here the rows of the round's
-        // queries of up to FLAT_SEG rows are cut into quads of 4 consecutive rows, numbered through the task; a step takes as
-        // many WHOLE queries as its 64 lanes hold quads for, lane l the l-th quad of the step, of whichever query owns it
-        // (binary search over the queries' first quads, in LDS).  The query's top bit-score meets in LDS (atomic max over its
-        // lanes), the top rows get their list slots by a scan over the step — quad order is file order — and the other values
-        // are fetched for the top rows only.  The bit-scores of step s + 1 are requested before step s is worked on.
-        // Roughly rows / 256 / 0.8 steps per task instead of one per 2 .. 16 queries; longer segments keep the long pass.
+        // queries (up to FLAT_SEG = MAX_TASK_SEG rows: all of them) are cut into units of FLAT_ROWS consecutive rows, numbered
+        // through the task; step s = units 64 s .. 64 s + 63, lane l its l-th unit, of whichever query owns it (binary search
+        // over the queries' first units, in LDS).  Two sub-passes over the steps, neither with a memory round trip per step:
+        //   A  the bit-scores of FLAT_DEPTH steps are in flight at a time; a lane keeps, per step, its own maximum and which of
+        //      its rows reach it (two registers), and the query's top bit-score meets in LDS (atomic max over its lanes);
+        //   B  a lane whose maximum is the query's marks its rows; the top rows get their list slots by a scan over the units —
+        //      unit order is file order — and what goes to the list is a lane descriptor, as in a ring round (top-row mask,
+        //      first row, position): the side records are gathered afterwards, one list entry per lane and all of a round's
+        //      requests in flight together (gather_list).
+        // A round takes the queries whose units end within FLAT_STEPS steps; the others come in the next round.
+        // (Round 3, first version: whole queries per step, quads, 256 rows, side records fetched inside the step — one round
+        // trip per step, and the segments of 257..512 rows in the unpipelined long pass: phase 1 was 77 % of a C5 task.)
         auto phase1_flat = [&]() {
             if constexpr (!RING) {
-            const uint32_t rows_all = L.seg[lane].y;             // this lane's query: 0 = nothing to do in this round
-            const uint32_t rows = rows_all <= FLAT_SEG ? rows_all : 0u;
-            const uint32_t nquad = (rows + 3u) >> 2;
-            uint32_t incl = nquad;
+            constexpr uint32_t UR = FLAT_ROWS, MAXS = FLAT_STEPS, DEPTH = FLAT_DEPTH;
+            static_assert(UR == 8u, "two 16-byte loads per lane");
+            static_assert(FLAT_SEG >= MAX_TASK_SEG, "the flat pass takes every segment of the task");
+            static_assert(DEPTH <= MAXS && MAXS * WAVE >= FLAT_SEG / UR, "a query's units fit one round");
+            const uint32_t rows = L.seg[lane].y;                 // this lane's query: 0 = nothing to do in this round
+            const uint32_t nunit = (rows + UR - 1u) / UR;
+            uint32_t incl = nunit;
             incl += (uint32_t)dpp<0x111>((int)incl);
             incl += (uint32_t)dpp<0x112>((int)incl);
             incl += (uint32_t)dpp<0x114>((int)incl);
@@ -951,7 +1020,13 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             const uint32_t t0 = (uint32_t)rl((int)incl, 15), t1 = (uint32_t)rl((int)incl, 31), t2 = (uint32_t)rl((int)incl, 47);
             const uint32_t r16 = (uint32_t)lane >> 4;
             incl += r16 == 0 ? 0u : (r16 == 1 ? t0 : (r16 == 2 ? t0 + t1 : t0 + t1 + t2));
-            const uint32_t q_end = incl, q_begin = incl - nquad;   // this query's quads in the round's numbering
+            const uint32_t q_end = incl, q_begin = incl - nunit;   // this query's units in the round's numbering
+            // the round: the queries whose units end within MAXS steps (a prefix of the pending ones; never empty: one query has
+            // at most 64 units)
+            const uint64_t out_m = __ballot(rows != 0u && q_end > MAXS * WAVE);
+            const uint32_t q_lim = out_m ? (uint32_t)__builtin_ctzll(out_m) : WAVE;
+            const uint32_t total = q_lim < WAVE ? (uint32_t)rl((int)q_begin, (int)q_lim) : (uint32_t)rl((int)q_end, WAVE - 1);
+            const uint32_t ns = (total + WAVE - 1u) / WAVE;      // steps of the round (<= MAXS)
             L.qs[lane] = q_begin;
             L.qm[lane] = INT_MIN;
             L.qk[lane] = 0u;
@@ -959,57 +1034,63 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            struct Quad { uint32_t q, oq, voff; int left; };
-            struct Step { uint32_t qb, S, n; };                  // queries [qa, qb), first quad, quads
-            // the step that starts at query qa: the whole queries whose quads end within 64 of its first quad (a contiguous
-            // range: the prefix sums do not decrease; one query never has more than 64 quads)
-            auto compose = [&](const uint32_t qa) {
-                Step T;
-                T.S = qa < WAVE ? (uint32_t)rl((int)q_begin, (int)qa) : 0u;
-                const uint64_t in = qa < WAVE ? (__ballot((uint32_t)lane >= qa && q_end <= T.S + WAVE) >> qa) : 0ull;
-                const uint32_t cnt = in == ~0ull ? WAVE : (uint32_t)__builtin_ctzll(~in);   // leading run of ones
-                T.qb = qa + cnt;
-                T.n = cnt ? (uint32_t)rl((int)q_end, (int)(T.qb - 1u)) - T.S : 0u;
-                return T;
-            };
-            auto quad_of = [&](const Step& T) {                  // lane's quad of the step: owner = the last query whose first quad is <= it
-                Quad Q;
-                const uint32_t g = T.S + (uint32_t)lane;
-                uint32_t q = 0;
+            // lane's unit of step st: owner = the last query whose first unit is <= it; packed as query | unit in the query << 6 |
+            // rows it holds (0 .. 8) << 12; the two loads are issued whether the unit exists or not (an offset the descriptor
+            // rejects: no memory access), so the wait counts of sub-pass A are exact
+            auto issue = [&](const uint32_t st, u32x4& lo4, u32x4& hi4, uint32_t& um) {
+                um = 0u;
+                uint32_t voff = 0xFFFFFFF0u;
+                int left = 0;
+                if (st < ns) {                                   // (wave-uniform)
+                    const uint32_t g = st * WAVE + (uint32_t)lane;
+                    uint32_t q = 0;
 #pragma unroll
-                for (uint32_t st = 32; st; st >>= 1) { const uint32_t c = q + st; if (L.qs[c] <= g) q = c; }
-                const uint2 sg = L.seg[q];
-                Q.q = q;
-                Q.oq = g - L.qs[q];
-                Q.left = (uint32_t)lane < T.n ? (int)umin(sg.y, FLAT_SEG) - (int)(4u * Q.oq) : 0;
-                Q.voff = Q.left > 0 ? (sg.x + 4u * Q.oq) * 4u : 0xFFFFFFF0u;
-                return Q;
+                    for (uint32_t sp = 32; sp; sp >>= 1) { const uint32_t c = q + sp; if (L.qs[c] <= g) q = c; }
+                    const uint2 sg = L.seg[q];
+                    const uint32_t oq = g - L.qs[q];
+                    left = g < total ? (int)sg.y - (int)(UR * oq) : 0;
+                    if (left > 0) { voff = (sg.x + UR * oq) * 4u; um = q | (oq << 6) | (umin((uint32_t)left, UR) << 12); }
+                }
+                lo4 = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, voff, 0, STREAM_AUX);
+                hi4 = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, left > 4 ? voff + 16u : 0xFFFFFFF0u, 0, STREAM_AUX);
             };
-            uint32_t running = fill, q_cut = WAVE, qa = 0;
-            Step T = compose(qa);
-            while (T.n == 0u && T.qb < WAVE && T.qb > qa) { qa = T.qb; T = compose(qa); }   // (leading queries without rows)
-            Quad Q = quad_of(T);
-            StepRegs R;
-            R.vbs = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, Q.voff, 0, STREAM_AUX);
-            while (T.n != 0u) {
-                // the next step's bit-scores travel while this one is worked on
-                uint32_t qn = T.qb;
-                Step TN = compose(qn);
-                while (TN.n == 0u && TN.qb < WAVE && TN.qb > qn) { qn = TN.qb; TN = compose(qn); }
-                Quad QN;
-                u32x4 vbn = {0u, 0u, 0u, 0u};
-                if (TN.n != 0u) { QN = quad_of(TN); vbn = __builtin_amdgcn_raw_buffer_load_b128(rs_bs, QN.voff, 0, STREAM_AUX); }
-                else { QN.q = 0; QN.oq = 0; QN.voff = 0xFFFFFFF0u; QN.left = 0; }
-                asm volatile("" ::"v"(R.vbs));
-                const int b0 = Q.left > 0 ? (int)R.vbs.x : INT_MIN, b1 = Q.left > 1 ? (int)R.vbs.y : INT_MIN;
-                const int b2 = Q.left > 2 ? (int)R.vbs.z : INT_MIN, b3 = Q.left > 3 ? (int)R.vbs.w : INT_MIN;
-                if (Q.left > 0) atomicMax(&L.qm[Q.q], imax(imax(b0, b1), imax(b2, b3)));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const int M = L.qm[Q.q];
-                const bool t0b = Q.left > 0 && b0 == M, t1b = Q.left > 1 && b1 == M, t2b = Q.left > 2 && b2 == M, t3b = Q.left > 3 && b3 == M;
-                const uint32_t tmask = (uint32_t)t0b | ((uint32_t)t1b << 1) | ((uint32_t)t2b << 2) | ((uint32_t)t3b << 3);
+            u32x4 ba[DEPTH], bb[DEPTH];
+            uint32_t um[MAXS];
+            int lmx[MAXS];
+#pragma unroll
+            for (uint32_t st = 0; st < MAXS; ++st) { um[st] = 0u; lmx[st] = INT_MIN; }
+#pragma unroll
+            for (uint32_t st = 0; st < DEPTH; ++st) issue(st, ba[st], bb[st], um[st]);
+            // ---- A: per step the lane's maximum and the rows that reach it; the query's maximum in LDS
+#pragma unroll
+            for (uint32_t st = 0; st < MAXS; ++st) {
+                if (st >= ns) break;
+                const u32x4 va = ba[st % DEPTH], vb = bb[st % DEPTH];
+                const uint32_t left = (um[st] >> 12) & 15u;
+                const uint32_t v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+                int bsv[UR], mx = INT_MIN;
+#pragma unroll
+                for (uint32_t r = 0; r < UR; ++r) { bsv[r] = left > r ? (int)v[r] : INT_MIN; mx = imax(mx, bsv[r]); }
+                uint32_t lmask = 0;
+#pragma unroll
+                for (uint32_t r = 0; r < UR; ++r) lmask |= (uint32_t)(left > r && bsv[r] == mx) << r;
+                um[st] |= lmask << 16;
+                lmx[st] = mx;
+                if (left) atomicMax(&L.qm[um[st] & 63u], mx);
+                if (st + DEPTH < MAXS) issue(st + DEPTH, ba[st % DEPTH], bb[st % DEPTH], um[st + DEPTH]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // ---- B: top rows, list slots, descriptors
+            uint32_t running = fill, q_cut = q_lim;
+#pragma unroll
+            for (uint32_t st = 0; st < MAXS; ++st) {
+                if (st >= ns) break;
+                const uint32_t q = um[st] & 63u, oq = (um[st] >> 6) & 63u;
+                const bool have = ((um[st] >> 12) & 15u) != 0u;
+                const int M = L.qm[q];
+                const uint32_t tmask = (have && lmx[st] == M) ? (um[st] >> 16) & 0xFFu : 0u;   // bit r = row r of the unit ties on the query's top score
                 const uint32_t c = (uint32_t)__builtin_popcount(tmask);
                 uint32_t in2 = c;
                 in2 += (uint32_t)dpp<0x111>((int)in2);
@@ -1019,20 +1100,16 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 const uint32_t k0 = (uint32_t)rl((int)in2, 15), k1 = (uint32_t)rl((int)in2, 31), k2 = (uint32_t)rl((int)in2, 47), k3 = (uint32_t)rl((int)in2, 63);
                 in2 += r16 == 0 ? 0u : (r16 == 1 ? k0 : (r16 == 2 ? k0 + k1 : k0 + k1 + k2));
                 const uint32_t idx0 = running + in2 - c;          // list slot of this lane's first top row
-                if (Q.left > 0 && Q.oq == 0u) L.meta[Q.q] = META_SLOW | idx0;   // the query's first slot (under the flag until the query is complete)
-                if (c) atomicAdd(&L.qk[Q.q], c);
-                const bool over = Q.left > 0 && idx0 + c > CAP;
+                if (have && oq == 0u) L.meta[q] = META_SLOW | idx0;   // the query's first slot (under the flag until the query is complete)
+                if (c) atomicAdd(&L.qk[q], c);
+                const bool over = have && idx0 + c > CAP;
                 const uint64_t over_m = __ballot(over);
                 const bool room = !over && c != 0u && (over_m == 0ull || (uint32_t)lane < (uint32_t)__builtin_ctzll(over_m));
-                fetch_rest(R, Q.voff, room ? tmask : 0u);
-                uint32_t idx = idx0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (room && ((tmask >> r) & 1u)) { put_entry(idx, R, r, 4u * Q.oq + (uint32_t)r); ++idx; }
-                }
-                if (over_m) { q_cut = (uint32_t)rl((int)Q.q, __builtin_ctzll(over_m)); break; }   // the list is full: from this query on, the next round
+                // the lane's descriptor, at the slot of its first top row: mask with row 0 in bit 31 (what gather_list counts
+                // through), first row relative to the task, position in the segment
+                if (room) L.rec[idx0] = make_uint4(__builtin_bitreverse32(tmask), L.seg[q].x + UR * oq, UR * oq, 0u);
+                if (over_m) { q_cut = (uint32_t)rl((int)q, __builtin_ctzll(over_m)); break; }   // the list is full: from this query on, the next round
                 running += k0 + k1 + k2 + k3;
-                T = TN; Q = QN; R.vbs = vbn;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -1041,8 +1118,8 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             // behind it stay marked for the next round (a query larger than the whole list makes no progress: worklist)
             const uint32_t m = L.meta[lane];
             if (rows != 0u && (uint32_t)lane < q_cut) L.meta[lane] = (m & 0xFFFFu) | (L.qk[lane] << 16);
-            fill = q_cut < WAVE ? (L.meta[q_cut] & 0xFFFFu) : running;
-            if (q_cut < WAVE) stop_q = q_cut;                    // (the long pass of this round is left out too)
+            fill = q_cut < q_lim ? (L.meta[q_cut] & 0xFFFFu) : running;
+            if (q_cut < WAVE) stop_q = q_cut;
             }
         };
         // ---------------- phase 1 of a ring task: lane = RPL consecutive rows, read from the LDS ring ----------------
@@ -1354,7 +1431,8 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 s = imax(s, __builtin_amdgcn_update_dpp(0, s, 0x143, 0xC, 0xF, false));   // row_bcast:31 into rows 2 and 3
                 s = imax(s, (int)carry);
                 carry = (uint32_t)rl(s, 63);
-                const uint32_t d0w = L.rec[s].x, d = L.rec[s].y;   // mask | (first row, position)
+                const uint4 dd = L.rec[s];                          // mask | (first row, position); kernel without the ring: mask | first row | position
+                const uint32_t d0w = dd.x, d = dd.y;
                 // the (idx - s + 1)-th set bit of the mask, counted from its top bit (= the lane's row 0)
                 uint32_t r = idx - (uint32_t)s, x = scan_rpl == 32u ? d0w : d0w >> 16, i = 0;
                 if (scan_rpl == 32u) {               // (wave-uniform)
@@ -1378,8 +1456,8 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     r -= low ? ch : 0u; x = low ? (x & 0x3u) : h; i += low ? 2u : 0u;
                 }
                 i += (r >= (x >> 1)) ? 1u : 0u;
-                const uint32_t row = (d >> DESC_SUB_BITS) + i;
-                gpos[u] = (d & ((1u << DESC_SUB_BITS) - 1u)) + i;
+                const uint32_t row = (RING ? (d >> DESC_SUB_BITS) : d) + i;
+                gpos[u] = (RING ? (d & ((1u << DESC_SUB_BITS) - 1u)) : dd.z) + i;
                 if (PACKED) g[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, valid ? row * 16u : 0xFFFFFFC0u, 0, GATHER_AUX);
                 else if (WIDE) {
                     g[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_tax, valid ? row * 24u : 0xFFFFFFC0u, 0, GATHER_AUX);
@@ -1458,6 +1536,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         fill = 0;
         stop_q = WAVE;
         bool ring_round = false;
+        bool list_round = false;   // the round's list holds lane descriptors (ring scan or flat pass): gather_list fills the entries in
         keyed = false;
         {
             const uint32_t rows = L.seg[lane].y;                    // this lane's query (0: empty, done, too long, or outside the span)
@@ -1482,7 +1561,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 if (c16 < best) { best = c16; short_seg = 16u; }
             }
 #endif
-            // Kernel without the ring: a round of mixed lengths takes the flat pass when its quads (twice: two passes) are fewer
+            // Kernel without the ring: the round takes the flat pass when its units (at ~80 % of the lanes, + the gather) are fewer
             // lane-steps than the cheapest width of the passes above plus their long pass
             bool flat_round = false;
             if constexpr (!RING) {
@@ -1498,16 +1577,9 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     best = umin(best, 8u * n32 + BLU_LONG_COST * (n128 - n32));
                     best = umin(best, 4u * n16 + BLU_LONG_COST * (n128 - n16));
                 }
-                uint32_t quads = rows <= FLAT_SEG ? (rows + 3u) >> 2 : 0u;
-                quads = (uint32_t)wave_sum_u32(quads);
-                // (flat: its quads once, at ~80 % of the lanes, + the long pass of the segments over FLAT_SEG rows)
-                const uint32_t n_flat_long = (uint32_t)__builtin_popcountll(__ballot(rows > FLAT_SEG));
-                // and only where short queries dominate (a mean of at most 64 rows): its steps cost more than a streamed step, which
-                // tables of mid-sized segments (uniform 1 .. 200 rows) do not earn back
-                const uint32_t n_live = (uint32_t)__builtin_popcountll(__ballot(rows != 0u));
-                flat_round = BLU_FLAT_PASS && quads != 0u && quads <= 16u * n_live &&
-                             quads + quads / 4u + 64u + BLU_LONG_COST * n_flat_long < best + BLU_LONG_COST * n_over;
-                if (flat_round) short_seg = FLAT_SEG;
+                const uint32_t units = (uint32_t)wave_sum_u32((rows + FLAT_ROWS - 1u) / FLAT_ROWS);
+                flat_round = BLU_FLAT_PASS && units != 0u && (BLU_FLAT_ALWAYS || units + units / 4u + 64u < best + BLU_LONG_COST * n_over);
+                if (flat_round) { short_seg = FLAT_SEG; scan_rpl = 16u; }   // (scan_rpl: the descriptor format gather_list reads)
             }
             const uint32_t longest = flat_round ? 0u : wave_max_u32(rows > short_seg ? 0u : rows);   // longest streamed segment of the task
             // (BLU_MIXED_RING: tasks that also hold longer segments through the ring, their whole chunks left out — correct
@@ -1534,9 +1606,12 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     }
                 }
             }
-            if (ring_round) {
+            list_round = ring_round || flat_round;
+            if (list_round) {
 #pragma unroll
                 for (uint32_t u = 0; u * WAVE < CAP; ++u) { const uint32_t i = u * WAVE + (uint32_t)lane; if (i < CAP) L.rec[i].x = 0u; }   // (no entry starts here)
+            }
+            if (ring_round) {
                 // (rows of the lanes' windows may overlap only inside one segment: every streamed segment at least a window long)
                 const bool all_full = __ballot(rows != 0u && rows <= short_seg && rows < scan_rpl) == 0ull;
                 if (scan_rpl == 32u) {
@@ -1544,12 +1619,13 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     else phase1_scan(std::integral_constant<uint32_t, 32>(), std::false_type(), lpq);
                 } else phase1_scan(std::integral_constant<uint32_t, 16>(), std::false_type(), lpq);
             }
+            else if (BLU_X_SKIP_P1) {}
             else if (flat_round) phase1_flat();
             else if (longest > 32u && longest <= 64u) phase1(std::integral_constant<uint32_t, 16>(), false);   // the C3 shape, specialised
             else if (longest) phase1(longest <= 16u ? 4u : (longest <= 32u ? 8u : 32u), longest >= (PACKED ? 9u : 25u));   // two-stage steps: measured break-even (packed records: 10 hits -2.5 %, 20 hits -17 %; columns: 20 hits +3 %, 30 hits -6 %)
             // queries phase 1 did not get to (the list filled up): marked for the next round, long ones included
             if (stop_q < WAVE && rows != 0u && ((uint32_t)lane >= stop_q || rows > short_seg)) L.meta[lane] = META_SLOW;
-            fill_ring = ring_round ? fill : 0u;                     // (what follows appends whole records, not lane descriptors)
+            fill_ring = list_round ? fill : 0u;                     // (what follows appends whole records, not lane descriptors)
             const uint64_t long_mask = __ballot(rows > short_seg);
             if (long_mask && stop_q == WAVE) phase1_long(long_mask);   // after the streamed pass: it overwrites their (empty) list heads
         }
@@ -1591,7 +1667,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 pref_task = next_task;
             }
         };
-        if (ring_round && !BLU_X_SKIP_GATHER) gather_list(prefetch_next);
+        if (list_round && !BLU_X_SKIP_GATHER) gather_list(prefetch_next);
         else prefetch_next();
         STAMP(2)   // next-task decision, gather issue + wait + list write
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1705,11 +1781,11 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             if (pend) {
                 bool done = true;
                 if (nrows == 0) { pack_status(ra, rb, BLU_ST_NO_HITS, 0xFFFFFFFFu); rec_kind = 1; }   // mod.rs:107-113
-                else if (nrows > MAX_TASK_SEG || !in_span) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
+                else if (nrows > MAX_TASK_SEG || !in_span) { if (!BLU_X_SKIP_PUSH) wl_q[atomicAdd(wl_cnt, 1u)] = (uint32_t)q; }
                 else if (m & META_SLOW) done = false;   // its step did not fit the list this round: again in the next one
                 else if (dn_flag == 1) mode = dn_k == 1 ? 2u : 0u;                                    // reduced by a dense step
                 else if (dn_flag == 2) { pack_status(ra, rb, dn_err, row0 + dn_pos); rec_kind = 1; }
-                else if (dn_flag == 3) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;
+                else if (dn_flag == 3) wl_q[atomicAdd(wl_cnt, 1u)] = (uint32_t)q;
                 else if (BLU_X_SKIP_2A) { mode = 2; r_row = L.rec[m & 0xFF].x & ROW_MASK; r_len = 5; minlen = 5; }
                 else if (err) { pack_status(ra, rb, err, row0 + err_pos); rec_kind = 1; }
                 else if (!PID32 && nan_pos != 0xFFFFFFFFu) { pack_status(ra, rb, BLU_ST_ERR_BAD_PIDENT, row0 + nan_pos); rec_kind = 1; }
@@ -1729,7 +1805,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        if (pend) worklist[atomicAdd(work_count, 1u)] = (uint32_t)q;   // a single step larger than the whole list
+        if (pend) wl_q[atomicAdd(wl_cnt, 1u)] = (uint32_t)q;   // a single step larger than the whole list
 
         // ---------------- phase 2c: lane = query, cutoff tests and the record ----------------
         if (BLU_X_SKIP_2C) { if (mode != 3) { pack_status(ra, rb, mode, r_row + minlen + r_pos + r_len + g_lo + g_hi); rec_kind = 1; } }
@@ -1992,7 +2068,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const uint32_t c = (uint32_t)lane + 64u * half, qc = c >> 1;
-            if (qc < nq && L.meta[qc]) {
+            if (qc < nq && L.meta[qc] && !BLU_X_SKIP_STORES) {
                 const uint4 v = rec[c];
                 const u32x4 w = {v.x, v.y, v.z, v.w};
                 __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, c * 16u, 0, RECORD_AUX);
@@ -2015,21 +2091,30 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     // also goes to a pinned host word: the next call on this table launches no worklist kernel when it was (next to) nothing
     // — a kernel boundary costs more than a C4 slice can afford — and if the queue is not empty after all, this block, the
     // last one running, works it off itself (every other block has finished and published its entries).
-    __shared__ uint32_t s_drain;
+    __shared__ uint32_t s_drain, s_last;
+    uint32_t* const s_cnt = s_lds[0].meta;   // (the queues' lengths, for the drain below: the first wave's task table is dead by now)
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
         const uint32_t ticket = atomicAdd(work_count + 1, 1u);
-        uint32_t drain = 0;
-        if (ticket == gridDim.x - 1) {
-            const uint32_t n = __hip_atomic_load(work_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == gridDim.x - 1 ? 1u : 0u;
+        s_drain = 0u;
+    }
+    __syncthreads();
+    if (s_last && wib == 0) {   // (one wave: lane = queue)
+        static_assert(WL_QUEUES == WAVE, "one lane per queue");
+        uint32_t* const c = work_count + WL_BASE + (uint32_t)lane * WL_STRIDE;
+        const uint32_t n_s = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t n = (uint32_t)wave_sum_u32(n_s);
+        __hip_atomic_store(c + 1, no_long ? 0u : n_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_cnt[lane] = n_s;
+        if (lane == 0) {
             if (host_len) __hip_atomic_store(host_len, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            drain = no_long ? n : 0u;
             __hip_atomic_store(work_count + 2, no_long ? 0u : n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(work_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(work_count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_drain = no_long ? n : 0u;
         }
-        s_drain = drain;
     }
     if (no_long) {
         __syncthreads();
@@ -2038,8 +2123,9 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the entries other blocks queued
             uint32_t* const slot = reinterpret_cast<uint32_t*>(&L.rec[0]);
             static_assert(sizeof(L.rec) >= SLOT_CAP * sizeof(uint32_t), "the list area holds the slots of a worklist query");
+            const uint32_t incl = wave_incl_scan_u32(s_cnt[lane]);
             for (uint32_t wi = (uint32_t)wib; wi < n; wi += WAVES_T)
-                consensus_of_long_query<STRAT, LAYOUT>(h, t, out, (uint64_t)__hip_atomic_load(worklist + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), slot, lane);
+                consensus_of_long_query<STRAT, LAYOUT>(h, t, out, (uint64_t)wl_entry(worklist, wl_cap, incl, wi), slot, lane);
         }
     }
 }
@@ -2348,11 +2434,14 @@ __global__ __launch_bounds__(BLOCK_B, BLU_B_WAVES_PER_SIMD) void blu_consensus_l
                                                                  const uint32_t* __restrict__ work_count) {
     __shared__ uint32_t s_slot[BLOCK_B / WAVE][SLOT_CAP];   // rows of the top group found so far (segments kept in registers)
     uint32_t* const slot = s_slot[__builtin_amdgcn_readfirstlane(threadIdx.x / WAVE)];
-    const uint32_t n_work = work_count[2];   // queue length published by the stream kernel's last block (0 when its waves drained the queue themselves)
+    const uint32_t n_work = work_count[2];   // entries of all queues, published by the stream kernel's last block (0 when its waves drained them themselves)
     const uint32_t wave = blockIdx.x * (blockDim.x / WAVE) + __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     const uint32_t n_waves = gridDim.x * (blockDim.x / WAVE);
     const int lane = lane_id();
-    for (uint32_t wi = wave; wi < n_work; wi += n_waves) consensus_of_long_query<STRAT, LAYOUT>(h, t, out, worklist[wi], slot, lane);
+    if (wave >= n_work) return;
+    const uint32_t cap = wl_capacity(h.n_queries);
+    const uint32_t incl = wave_incl_scan_u32(work_count[WL_BASE + (uint32_t)lane * WL_STRIDE + 1u]);   // lane = queue: its published length
+    for (uint32_t wi = wave; wi < n_work; wi += n_waves) consensus_of_long_query<STRAT, LAYOUT>(h, t, out, (uint64_t)wl_entry(worklist, cap, incl, wi), slot, lane);
 }
 
 // ===============================================================================

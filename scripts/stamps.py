@@ -10,10 +10,14 @@ import argparse
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C3"); ap.add_argument("--hits-per-query", type=int, default=0); ap.add_argument("--queries", type=int, default=0)
 ap.add_argument("--top-group", default="geo")
+ap.add_argument("--deep", type=int, default=-1, help="override the config's lineage depth class (0 / 1)")
+ap.add_argument("--taxa", type=int, default=0, help="override the number of taxids")
 a = ap.parse_args()
 cfg = dict(synth.CONFIGS[a.config]); seed = synth.SEEDS[a.config]
 if a.hits_per_query: cfg["hits_per_query"] = a.hits_per_query
 if a.queries: cfg["n_queries"] = a.queries
+if a.deep >= 0: cfg["deep"] = bool(a.deep)
+if a.taxa: cfg["n_taxa"] = a.taxa
 tax = synth.make_taxonomy(cfg["n_taxa"], seed, deep=cfg["deep"])
 t = engine.Taxonomy(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, taxon="custom", custom=CUSTOM, device=0)
 hits = synth.make_hits(tax, cfg["n_queries"], seed, cfg["hits_per_query"], zipf=cfg["zipf"], device="cuda", columns="milli", top_group=a.top_group)
