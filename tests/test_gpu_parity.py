@@ -761,6 +761,30 @@ def test_both_builds_of_the_stream_kernel_give_the_same_records(kind, monkeypatc
                 _assert_records_equal(got, exp)
 
 
+@pytest.mark.parametrize("top_group", ["all", "zymo"])
+def test_flat_pass_with_a_list_that_fills_up(top_group, monkeypatch):
+    """The flat pass of the kernel without the ring (units of 8 rows dealt to the lanes, two sub-passes, lane descriptors +
+    gather) on tables that push it through its corners: mixed segment lengths of 1..600 rows whose top groups are whole
+    segments ("all": the list fills up inside a step, queries come again in the next round, top groups larger than the list
+    end on the worklist, segments over 512 rows go there directly) or follow the reference's real histogram ("zymo")."""
+    monkeypatch.setenv("BLU_STREAM_KIND", "noring")
+    tax = synth.make_taxonomy(3000, 91)
+    t = _engine_tax(tax, "custom", H.CUSTOM_16S)
+    h = synth.make_hits(tax, 2200, 92, None, zipf=(0.7, 1, 600), top_group=top_group, p_unmatched=0.001).numpy()
+    rows = t.engine_rows(h["tax_row"])
+    pm = np.round(h["pident"] * 1000).astype(np.uint32)
+    h = dict(h, pident=pm / 1000.0)
+    lens = np.diff(h["seg_off"].astype(np.int64))
+    assert (lens > 512).any() and ((lens > 256) & (lens <= 512)).any() and (lens <= 8).any()
+    for strategy in ("relaxed", "cautious"):
+        exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S, threads=8)
+        for packed in (False, True):
+            got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None, h["align_len"], h["acc_rank"], strategy=strategy,
+                                            pident_milli=pm, packed=packed)
+            _assert_records_equal(got, exp)
+        _assert_records_equal(engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], strategy=strategy), exp)
+
+
 def test_a_queue_that_turns_up_after_an_empty_one_is_still_worked_off():
     """The call after a run that left the worklist empty launches no worklist kernel (a kernel boundary is a tenth of a C4
     slice).  If the same buffers then hold a table WITH long segments, the stream kernel's last block drains the queue
