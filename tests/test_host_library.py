@@ -15,6 +15,13 @@ from tests import helpers as H
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_the_driver_build_hook_runs():
+    """__graft_entry__.build() is what the driver calls to check that everything compiles (here, without a GPU): an
+    incremental `make` of the library and of the oracle, then the ABI version of the header against the library's."""
+    import __graft_entry__ as g
+    g.build()
+
+
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "blu_consensus.h")).read()
     declared = set(re.findall(r"\b(blu_[a-z0-9_]+)\s*\(", hdr))
