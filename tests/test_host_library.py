@@ -270,3 +270,16 @@ def test_division_free_milli_percent_conversion_is_exact_for_17_bit_values():
         q = float(Fraction(k) * y)
         r = float(Fraction(k) - Fraction(q) * 1000)
         assert float(Fraction(q) + Fraction(r) * y) == k / 1000.0, k
+
+
+def test_worklist_queues_fit_the_buffer_the_library_allocates():
+    """consensus_kernel.hip: 64 worklist queues (WL_QUEUES), a task appends to queue task % 64, at most its 64 queries; a queue
+    holds wl_capacity(n_queries) = ceil(n_tasks / 64) * 64 entries and the 64 of them lie back to back in the buffer api.cpp
+    allocates (n_queries + 8192 words).  The arithmetic, for small, odd and huge query counts."""
+    for nq in [0, 1, 63, 64, 65, 4095, 4096, 4097, 10**6, 10**7, 10**7 + 1, 2**32 - 2]:
+        n_tasks = (nq + 63) // 64
+        cap = (n_tasks + 63) // 64 * 64
+        for s_ in (0, 1, 63):
+            tasks_of_queue = len(range(s_, n_tasks, 64))
+            assert tasks_of_queue * 64 <= cap
+        assert 64 * cap <= nq + 8192
