@@ -150,6 +150,14 @@ __device__ __forceinline__ int wave_min_i32(int x) {
     ROW_REDUCE(x, imin)
     return imin(imin(rl(x, 0), rl(x, 16)), imin(rl(x, 32), rl(x, 48)));
 }
+// Layouts (bit = LAYOUT) whose phase 2c reads the node id of the reported level back from the reference row's line — an L2
+// hit behind the eight loads that brought it — instead of keeping the row's 20 node ids in registers through the level
+// tests.  Measured, one box per pair: f64 side records 1.129 -> 1.031 ms (their build had 20 B/lane of scratch, none with
+// this), milli-percent columns 1.608 -> 1.437 (24 -> 8 B), f64 columns 1.410 -> 1.425 and the packed layout 0.953 -> 0.968
+// (no scratch either way: the extra round trip shows) — hence layout by layout: 1 and 3.
+#ifndef BLU_NODE_RELOAD_LAYOUTS
+#define BLU_NODE_RELOAD_LAYOUTS 0xAu
+#endif
 #ifndef BLU_FLAT_ALWAYS
 #define BLU_FLAT_ALWAYS 0   // experiment: every round of the kernel without the ring takes the flat pass
 #endif
@@ -1821,6 +1829,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             // pushed it out of L2 in between.)
             const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
             const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
+            constexpr bool NODE_RELOAD = ((BLU_NODE_RELOAD_LAYOUTS >> LAYOUT) & 1u) != 0u;
             uint4 w[8];
 #if BLU_REF_NT
             {
@@ -1836,7 +1845,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             }
 #else
 #pragma unroll
-            for (int k = 0; k < 8; ++k) w[k] = ref4[k];
+            for (int k = 0; k < (NODE_RELOAD ? 3 : 8); ++k) w[k] = ref4[k];
 #endif
             // What the finalisation needs per LEVEL depends on the row's shape only (TaxDev::kthr: threshold, rank code and
             // max-allowed-rank bit in one word per level).  In the packed layout the side record of the reference hit carries
@@ -2013,6 +2022,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 const uint32_t nid[20] = {w[2].w, w[3].x, w[3].y, w[3].z, w[3].w, w[4].x, w[4].y, w[4].z, w[4].w, w[5].x,
                                           w[5].y, w[5].z, w[5].w, w[6].x, w[6].y, w[6].z, w[6].w, w[7].x, w[7].y, w[7].z};
                 auto node_of = [&](uint32_t j) {
+                    if (NODE_RELOAD) return ref[BLU_ROW_NODE_BASE + j];   // (read back from the row's line: see BLU_NODE_RELOAD_LAYOUTS)
                     uint32_t v = 0;
                     if (j >= 20) v = ref[BLU_ROW_NODE_BASE + j];
 #pragma unroll
