@@ -155,6 +155,11 @@ __device__ __forceinline__ int wave_min_i32(int x) {
 // tests.  Measured, one box per pair: f64 side records 1.129 -> 1.031 ms (their build had 20 B/lane of scratch, none with
 // this), milli-percent columns 1.608 -> 1.437 (24 -> 8 B), f64 columns 1.410 -> 1.425 and the packed layout 0.953 -> 0.968
 // (no scratch either way: the extra round trip shows) — hence layout by layout: 1 and 3.
+// ... and every build of the kernel without the ring (128 VGPRs: its packed build goes from 60 to 40 B/lane of scratch;
+// uniform 1..200-row segments 0.947 -> 0.888 ms, C5 0.450 -> 0.441)
+#ifndef BLU_NODE_RELOAD_NORING
+#define BLU_NODE_RELOAD_NORING 1
+#endif
 #ifndef BLU_NODE_RELOAD_LAYOUTS
 #define BLU_NODE_RELOAD_LAYOUTS 0xAu
 #endif
@@ -1829,7 +1834,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             // pushed it out of L2 in between.)
             const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
             const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
-            constexpr bool NODE_RELOAD = ((BLU_NODE_RELOAD_LAYOUTS >> LAYOUT) & 1u) != 0u;
+            constexpr bool NODE_RELOAD = ((BLU_NODE_RELOAD_LAYOUTS >> LAYOUT) & 1u) != 0u || (!RING && BLU_NODE_RELOAD_NORING);
             uint4 w[8];
 #if BLU_REF_NT
             {
@@ -2537,7 +2542,7 @@ static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hip
         hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT, false>), dim3(grid), dim3(block_n), 0, s, hits, tax, out, worklist, work_count, forced, host_len);
     }
     // 32 waves per CU: the kernel is latency-bound per query (block size 256 / 512 / 1024: 1.11 / 1.135 / 1.14 ms on C5)
-    const uint32_t grid_b = (uint32_t)(num_cus > 0 ? num_cus : 256) * (2048u / BLOCK_B);
+    const uint32_t grid_b = (uint32_t)(num_cus > 0 ? num_cus : 256) * (BLU_B_WAVES_PER_SIMD * 4u * WAVE / BLOCK_B);
     if (!no_long) hipLaunchKernelGGL((blu_consensus_long_kernel<STRAT, LAYOUT>), dim3(grid_b), dim3(BLOCK_B), 0, s, hits, tax, out, worklist, work_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("kernel launch failed: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
