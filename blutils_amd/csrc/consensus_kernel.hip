@@ -157,6 +157,9 @@ __device__ __forceinline__ int wave_min_i32(int x) {
 // (no scratch either way: the extra round trip shows) — hence layout by layout: 1 and 3.
 // ... and every build of the kernel without the ring (128 VGPRs: its packed build goes from 60 to 40 B/lane of scratch;
 // uniform 1..200-row segments 0.947 -> 0.888 ms, C5 0.450 -> 0.441)
+#ifndef BLU_NODE_RELOAD_CAUTIOUS
+#define BLU_NODE_RELOAD_CAUTIOUS 1   // ... and every cautious build (12 B/lane of scratch in its packed ring build: C3 cautious 0.988 -> 0.921 ms, what relaxed takes)
+#endif
 #ifndef BLU_NODE_RELOAD_NORING
 #define BLU_NODE_RELOAD_NORING 1
 #endif
@@ -1834,7 +1837,8 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             // pushed it out of L2 in between.)
             const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
             const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
-            constexpr bool NODE_RELOAD = ((BLU_NODE_RELOAD_LAYOUTS >> LAYOUT) & 1u) != 0u || (!RING && BLU_NODE_RELOAD_NORING);
+            constexpr bool NODE_RELOAD = ((BLU_NODE_RELOAD_LAYOUTS >> LAYOUT) & 1u) != 0u || (!RING && BLU_NODE_RELOAD_NORING) ||
+                                         (STRAT == BLU_CAUTIOUS && BLU_NODE_RELOAD_CAUTIOUS);
             uint4 w[8];
 #if BLU_REF_NT
             {
