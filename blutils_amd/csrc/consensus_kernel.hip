@@ -157,6 +157,12 @@ __device__ __forceinline__ int wave_min_i32(int x) {
 // (no scratch either way: the extra round trip shows) — hence layout by layout: 1 and 3.
 // ... and every build of the kernel without the ring (128 VGPRs: its packed build goes from 60 to 40 B/lane of scratch;
 // uniform 1..200-row segments 0.947 -> 0.888 ms, C5 0.450 -> 0.441)
+// Where the row is not read back: levels whose node ids are kept in registers through phase 2c (the pick of the reported
+// level's id is a compare/select pair per kept level); a deeper reported level is read back.  12 instead of all 20 a
+// 128-byte row holds: C3 (8 levels) -1.0 %, zymo-like -2.1 %, C4 slice -1.3 % on one box (9: -0.4 / -2.1 / -1.3).
+#ifndef BLU_NID_REGS
+#define BLU_NID_REGS 12
+#endif
 #ifndef BLU_NODE_RELOAD_CAUTIOUS
 #define BLU_NODE_RELOAD_CAUTIOUS 1   // ... and every cautious build (12 B/lane of scratch in its packed ring build: C3 cautious 0.988 -> 0.921 ms, what relaxed takes)
 #endif
@@ -1839,6 +1845,10 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
             constexpr bool NODE_RELOAD = ((BLU_NODE_RELOAD_LAYOUTS >> LAYOUT) & 1u) != 0u || (!RING && BLU_NODE_RELOAD_NORING) ||
                                          (STRAT == BLU_CAUTIOUS && BLU_NODE_RELOAD_CAUTIOUS);
+            // node ids of the first NID_REGS levels stay in registers (words of the row that are loaded anyway); when a deeper level
+            // is the reported one its node id is read back from the row's line
+            constexpr uint32_t NID_REGS = NODE_RELOAD ? 0u : (uint32_t)BLU_NID_REGS;
+            static_assert(NID_REGS <= 20u, "a 128-byte row holds 20 node ids");
             uint4 w[8];
 #if BLU_REF_NT
             {
@@ -1854,7 +1864,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             }
 #else
 #pragma unroll
-            for (int k = 0; k < (NODE_RELOAD ? 3 : 8); ++k) w[k] = ref4[k];
+            for (int k = 0; k < (NODE_RELOAD ? 3 : (int)((BLU_ROW_NODE_BASE + NID_REGS + 3u) / 4u)); ++k) w[k] = ref4[k];
 #endif
             // What the finalisation needs per LEVEL depends on the row's shape only (TaxDev::kthr: threshold, rank code and
             // max-allowed-rank bit in one word per level).  In the packed layout the side record of the reference hit carries
@@ -2028,14 +2038,17 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     else { rank = packed_rank(v); mar = packed_mar(v); }
                 };
                 // node id of level j: words 11..30 of the line are in registers, deeper levels are read from the row
-                const uint32_t nid[20] = {w[2].w, w[3].x, w[3].y, w[3].z, w[3].w, w[4].x, w[4].y, w[4].z, w[4].w, w[5].x,
-                                          w[5].y, w[5].z, w[5].w, w[6].x, w[6].y, w[6].z, w[6].w, w[7].x, w[7].y, w[7].z};
                 auto node_of = [&](uint32_t j) {
                     if (NODE_RELOAD) return ref[BLU_ROW_NODE_BASE + j];   // (read back from the row's line: see BLU_NODE_RELOAD_LAYOUTS)
                     uint32_t v = 0;
-                    if (j >= 20) v = ref[BLU_ROW_NODE_BASE + j];
+                    if (j >= NID_REGS) v = ref[BLU_ROW_NODE_BASE + j];
 #pragma unroll
-                    for (uint32_t i = 0; i < 20; ++i) v = (j == i) ? nid[i] : v;
+                    for (uint32_t i = 0; i < NID_REGS; ++i) {
+                        const uint4 q4 = w[(BLU_ROW_NODE_BASE + i) / 4u];
+                        const uint32_t m4 = (BLU_ROW_NODE_BASE + i) % 4u;
+                        const uint32_t x = m4 == 0u ? q4.x : (m4 == 1u ? q4.y : (m4 == 2u ? q4.z : q4.w));
+                        v = (j == i) ? x : v;
+                    }
                     return v;
                 };
                 if (agree) A = F;                                                  // single hit / single-flag branch (:74-75)

@@ -785,6 +785,31 @@ def test_flat_pass_with_a_list_that_fills_up(top_group, monkeypatch):
         _assert_records_equal(engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], strategy=strategy), exp)
 
 
+@pytest.mark.parametrize("kind", ["ring", "noring"])
+def test_reported_levels_beyond_the_node_ids_kept_in_registers(kind, monkeypatch):
+    """Phase 2c keeps the node ids of the first 12 levels of the reference row in registers (packed relaxed ring build) or
+    none at all (the other builds) and reads a deeper reported level's id back from the row: deep lineages on a uniform
+    50-hit table, every layout, both strategies, both builds of the stream kernel, against the oracle — with reported levels
+    on both sides of the 12."""
+    monkeypatch.setenv("BLU_STREAM_KIND", kind)
+    tax = synth.make_taxonomy(6000, 93, deep=True)
+    t = _engine_tax(tax, "custom", H.CUSTOM_16S)
+    h = synth.make_hits(tax, 3000, 94, 50, p_unmatched=0.001).numpy()
+    rows = t.engine_rows(h["tax_row"])
+    pm = np.round(h["pident"] * 1000).astype(np.uint32)
+    h = dict(h, pident=pm / 1000.0)
+    for strategy in ("relaxed", "cautious"):
+        exp = H.columnar(tax, h, "custom", strategy, H.CUSTOM_16S, threads=8)
+        ok = exp["status"] <= 1
+        last = np.array([int(m).bit_length() - 1 for m in exp["level_mask"][ok]])
+        assert (last >= 12).sum() > 50 and (last < 12).sum() > 50, (int((last >= 12).sum()), int((last < 12).sum()))
+        _assert_records_equal(engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, h["pident"], h["align_len"], h["acc_rank"], strategy=strategy), exp)
+        for packed in (False, True, "wide"):
+            got = engine.run_consensus_host(t, h["seg_off"], h["bitscore"], rows, None if packed != "wide" else h["pident"], h["align_len"], h["acc_rank"],
+                                            strategy=strategy, pident_milli=pm if packed != "wide" else None, packed=packed)
+            _assert_records_equal(got, exp)
+
+
 def test_a_queue_that_turns_up_after_an_empty_one_is_still_worked_off():
     """The call after a run that left the worklist empty launches no worklist kernel (a kernel boundary is a tenth of a C4
     slice).  If the same buffers then hold a table WITH long segments, the stream kernel's last block drains the queue
