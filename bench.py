@@ -46,6 +46,11 @@ LAYOUT_TEXT = {"packed": "bit-score column + 16-byte side records, perc_identity
                "f64": "five columns, perc_identity as f64 (24 B/hit)"}
 
 
+# the arithmetic the path computes in, per layout: integer compares on bit-scores (i32) and milli-percent identities / packed
+# sort keys (u32), one f64 conversion per record; the f64 layouts compare f64 identities where they are off the milli-percent grid
+DTYPE_TEXT = {"packed": "i32/u32", "milli": "i32/u32", "packed64": "i32/u32+f64", "f64": "i32/u32+f64"}
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -130,10 +135,62 @@ SECONDARY = (
     dict(name="C3 shape, all 50 hits of every query tied (table read in full), 2 M queries", config="C3", top_group="all", queries=2000000, pident="packed"),
     dict(name="C3 in the canonical f64 layout (five columns, 24 B/hit)", config="C3", pident="f64"),
     dict(name="C3 with f64 side records (blu_hits_pack64, 28 B/hit)", config="C3", pident="packed64"),
+    dict(name="C3 as five columns with perc_identity as milli-percent u32 (20 B/hit)", config="C3", pident="milli"),
     dict(name="C4 slice: one eighth of C3 (1.25 M queries), what one rank of the 8-GPU run holds", config="C3", queries=1250000, pident="packed"),
     dict(name="C5: 1 M queries, Zipf 1..5000 hits, deep lineages", config="C5", pident="packed"),
     dict(name="C2: 100 k queries x 50 hits, 50 k taxids, replayed from a HIP graph", config="C2", pident="packed", graph=True),
 )
+
+
+def stream_read_ceiling(torch, gib: float = 4.0):
+    """Read-only HBM streaming rate of THIS box in GB/s (scripts/probe/stream_probe.hip, built by __graft_entry__.build() as
+    blutils_amd/lib/libblu_probe.so): the ceiling SURVEY 8d asks to quote next to the 8 TB/s spec peak.  None if the probe
+    library is not there."""
+    import ctypes
+    so = os.path.join(ROOT, "blutils_amd", "lib", "libblu_probe.so")
+    if not os.path.exists(so):
+        return None
+    L = ctypes.CDLL(so)
+    L.probe_read.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    nbytes = int(gib * (1 << 30))
+    buf = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda").fill_(1)
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    best = 0.0
+    for grid in (2048, 4096, 8192):
+        for _ in range(2):
+            L.probe_read(buf.data_ptr(), nbytes, sink.data_ptr(), grid, s)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            L.probe_read(buf.data_ptr(), nbytes, sink.data_ptr(), grid, s)
+        b.record()
+        torch.cuda.synchronize()
+        best = max(best, nbytes * 5 / (a.elapsed_time(b) * 1e-3) / 1e9)
+    del buf
+    torch.cuda.empty_cache()
+    return best
+
+
+def time_pack(engine, torch, np, eng_tax, cols, wide: bool, n_hits: int, reps: int = 5):
+    """blu_hits_pack / blu_hits_pack64 on the timed table's columns, HIP events on the launch stream: what a caller that
+    holds SoA columns pays once per table before the packed layout's runs.  Bytes: the four 4-byte columns (f64 layout:
+    8 for perc_identity) read + the record written; the 2-byte shape hint per row comes from a table that stays in L2."""
+    outp = engine.pack_hits_device(eng_tax, cols, wide=wide)      # (warm-up; allocates the records)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        outp = engine.pack_hits_device(eng_tax, cols, wide=wide)
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    del outp
+    torch.cuda.empty_cache()
+    nbytes = ((20 + 24) if wide else (16 + 16)) * n_hits
+    return {"pack_ms": ms, "bytes": nbytes, "achieved": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "unit": "GB/s", "note": "blu_hits_pack on this table's columns (columns read + records written per hit row), once per table; "
+                                    "not inside ms_per_step — the GPU parser and the pipeline emit the packed layout directly"}
 
 
 def run_secondary(args, synth, engine, torch, np, dev, local_rank, custom, reuse):
@@ -201,6 +258,45 @@ def run_secondary(args, synth, engine, torch, np, dev, local_rank, custom, reuse
     return out_list
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, the same argv), rank 0's stdout is this process's stdout.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    share = os.environ.get("BLU_BENCH_SHARE_GPU") == "1"
+    try:
+        import torch
+        have = torch.cuda.device_count()            # (counting devices does not initialise the GPU on this image)
+    except Exception:
+        have = 0
+    if have < n and not share:
+        log(f"[bench] --gpus {n}: this node shows {have} GPU(s)")
+        return 2
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if bad:                                      # a rank that died leaves the others in a barrier: end them (by PID)
+            rc = abs(bad[0])
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,6 +329,15 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (N = 1: the other workloads of SECONDARY; N > 1: the weak-scaling figure)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Launched without a launcher: start the N rank processes here.  This parent makes no GPU call of any kind before
+        # (or after) it spawns them — fresh children, no re-exec of a process that has touched the card.
+        raise SystemExit(self_launch(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus and os.environ.get("BLU_BENCH_FORCE_DIST") != "1":
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself; or torch.distributed.run --nproc-per-node N)")
 
     import numpy as np
     import torch
@@ -393,6 +498,13 @@ def main():
                                       f"queries, {dt:.2f} s wall"}
             log(f"[bench] cpu baseline: {cpu_baseline['value']:.4f} Mq/s on {cores} threads ({dt:.2f}s)")
 
+    pack_info = None
+    if rank == 0 and world == 1 and args.pident in ("packed", "packed64") and not args.no_secondary:
+        pc = {k: cols[k] for k in ("tax_row", "align_len", "acc_rank")}
+        pc["pident" if args.pident == "packed64" else "pident_milli"] = cols["pident" if args.pident == "packed64" else "pident_milli"]
+        pack_info = time_pack(engine, torch, np, eng_tax, pc, args.pident == "packed64", Hn)
+        log(f"[bench] pack: {pack_info['pack_ms']:.3f} ms for {Hn} rows ({pack_info['achieved']:.0f} GB/s)")
+
     total_q = Q
     if distributed:
         tq = torch.tensor([Q], dtype=torch.int64, device=cdev)
@@ -427,6 +539,16 @@ def main():
         hits = None
         torch.cuda.empty_cache()
         other_workloads = run_secondary(args, synth, engine, torch, np, dev, local_rank, custom, {"C3": (tax, eng_tax)})
+
+    ceiling = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        if other_workloads is None:                  # (the table is still resident: make room for the probe's buffer)
+            state["hd"] = state["out"] = None
+            hd = cols = out = hits = None
+            torch.cuda.empty_cache()
+        ceiling = stream_read_ceiling(torch)
+        if ceiling:
+            log(f"[bench] stream-read ceiling of this box: {ceiling:.0f} GB/s")
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -468,6 +590,13 @@ def main():
             roofline["traffic_over_useful"] = traffic / useful
         if traffic_note:
             roofline["traffic_note"] = traffic_note
+        if ceiling:
+            roofline["stream_read_ceiling"] = ceiling          # GB/s, measured in this run on this box (read-only nt stream)
+            roofline["frac_of_ceiling"] = gbps(useful) / ceiling
+            if traffic:
+                roofline["traffic_frac_of_ceiling"] = gbps(traffic) / ceiling
+        if pack_info:
+            roofline["pack"] = pack_info
         hpq = cfg["hits_per_query"] if cfg["zipf"] is None else "Zipf" + str(cfg["zipf"])
         what = (f"{args.config}: {Q_table} queries x {hpq} hits" +
                 (f" per GPU" if scaling == "weak" or world == 1 else f" in ONE table sharded over {world} GPUs (BASELINE config 4)") +
@@ -477,7 +606,7 @@ def main():
             "metric": "Mqueries/sec consensus (synthetic outfmt-6 hit table)",
             "value": value, "unit": "Mqueries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "i32+f64", "data": "synthetic",
+            "dtype": DTYPE_TEXT[args.pident], "data": "synthetic",
             "config": {"workload": what, "queries_total": total_q, "queries_rank0": Q, "hit_rows_rank0": Hn, "taxids": tax.n,
                        "strategy": args.strategy, "taxon": args.taxon, "top_group": args.top_group, "pident_layout": args.pident,
                        "bytes_per_hit": row_bytes, "seed": hex(seed), "generator_version": synth.GENERATOR_VERSION,

@@ -62,3 +62,44 @@ def test_two_rank_gloo_sharding():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+# ---- bench.py --gpus N: the launcher -------------------------------------------------------------------------------------
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_is_not_decorative():
+    """`--gpus N` with no launcher either starts N ranks or fails: it never prints an n_gpus-1 line."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU node runs the real thing (test_bench_self_launch_two_ranks_on_one_card covers one GPU)")
+    r = _bench(["--gpus", "2", "--steps", "1"])
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "GPU" in r.stderr
+    # a launcher's world size that disagrees with --gpus is refused before anything is measured
+    r = _bench(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_on_one_card():
+    """`python bench.py --gpus 2` starts its two ranks itself (fresh children; the parent makes no GPU call).  On a one-GPU box
+    the ranks share cuda:0 and meet over gloo (BLU_BENCH_SHARE_GPU=1): what is checked is the launcher, the cut of ONE table
+    over the ranks, rank 0's parity gate on its shard and the fields of the line — not a scaling figure."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--queries", "200000", "--taxa", "50000", "--cpu-sample", "20000",
+                "--no-cpu-baseline", "--no-secondary"], {"BLU_BENCH_SHARE_GPU": "1"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["queries_total"] == 200000
+    assert d["config"]["queries_rank0"] == 100000 and "world_size 2" in d["config"]["process_group"]
