@@ -13,7 +13,7 @@ EXPORTS = (
     "blu_abi_version", "blu_last_error", "blu_consensus_run_multi", "blu_shard_ranges", "blu_taxonomy_create", "blu_taxonomy_destroy", "blu_taxonomy_n_tax",
     "blu_taxonomy_n_shapes", "blu_taxonomy_n_rank_codes", "blu_taxonomy_max_depth", "blu_taxonomy_device_bytes",
     "blu_taxonomy_rank_name", "blu_taxonomy_row_cutoffs", "blu_taxonomy_lookup", "blu_taxonomy_row_map", "blu_consensus_run",
-    "blu_consensus_last_launch", "blu_hits_pack", "blu_hits_pack64",
+    "blu_consensus_last_launch", "blu_hits_pack", "blu_hits_pack64", "blu_taxonomy_shared_levels", "blu_taxonomy_trim",
 )
 # include/blu_pipeline.h
 PIPELINE_EXPORTS = ("blu_build_consensus_identities", "blu_free_text", "blu_custom_taxon_from_file", "blu_ingest_only",
@@ -95,6 +95,11 @@ def lib() -> C.CDLL:
             continue
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [C.c_void_p, C.POINTER(Hits), C.c_void_p, C.c_void_p]
+    if hasattr(L, "blu_taxonomy_shared_levels"):
+        L.blu_taxonomy_shared_levels.restype = C.c_int
+        L.blu_taxonomy_shared_levels.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+        L.blu_taxonomy_trim.restype = C.c_int
+        L.blu_taxonomy_trim.argtypes = [C.c_void_p]
     L.blu_consensus_last_launch.restype = C.c_int
     L.blu_consensus_last_launch.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     _lib = L

@@ -18,6 +18,10 @@
 
 using namespace blu;
 
+#ifndef BLU_STAGE_KEEP_BYTES
+#define BLU_STAGE_KEEP_BYTES (4ull << 30)   // staging buffers the handle keeps between host-pointer calls (a 200 M-row packed table)
+#endif
+
 #define HIP_TRY(expr)                                                              \
     do {                                                                           \
         hipError_t _e = (expr);                                                    \
@@ -30,10 +34,12 @@ using namespace blu;
 
 // The stream-kernel kind the handle's last table wanted, as far as the device has reported it (pinned word, read without
 // synchronisation); 0 = classify on the device again: the first calls, and every 64th.
-// The remembered kind belongs to ONE table: it is keyed by the offsets pointer and the query count of the call that
-// classified, so a handle used in turn on tables of different shape (or on the chunks of a staged table) classifies each
-// of them instead of launching the other table's kind.
-static uint32_t known_kind(const blu_taxonomy* tax, const void* seg_off, uint64_t n_queries) {
+// The remembered kind — and the "its last run queued next to nothing" bit that lets a call skip the worklist kernel — belong
+// to ONE table, recognised by the device addresses of its offsets, bit-scores and side values and by its query and row counts.
+// staged = the table sits in the handle's own staging buffers (host-pointer path): those addresses are the same for every
+// host table, so the kind is still remembered (a stale kind costs time only — and never much: both kinds take every table)
+// but the worklist kernel is always launched.
+static uint32_t known_kind(const blu_taxonomy* tax, const HitsDev& h, bool staged) {
     // BLU_STREAM_KIND=ring | noring: that build for every table (tests: both builds must give the same records on any table)
     uint32_t forced_kind = 0;
     if (const char* env = getenv("BLU_STREAM_KIND")) {
@@ -41,20 +47,23 @@ static uint32_t known_kind(const blu_taxonomy* tax, const void* seg_off, uint64_
         if (strcmp(env, "noring") == 0) forced_kind = 2u;
     }
     const uint64_t call = __atomic_fetch_add(&tax->ws_calls, 1, __ATOMIC_RELAXED);
-    const bool same_table = tax->ws_kind_key_ptr == seg_off && tax->ws_kind_key_n == n_queries;
+    const void* side = h.packed ? (const void*)h.packed : h.packed64 ? (const void*)h.packed64 : (const void*)h.tax_row;
+    const bool same_table = tax->ws_kind_key_ptr[0] == h.seg_off && tax->ws_kind_key_ptr[1] == h.bitscore && tax->ws_kind_key_ptr[2] == side &&
+                            tax->ws_kind_key_n[0] == h.n_queries && tax->ws_kind_key_n[1] == h.n_hits;
     if (!tax->ws_kind_host || (call & 63u) == 0 || !same_table) {
         if (tax->ws_kind_host) {   // (until the device reports this table's kind and queue length)
             __atomic_store_n(tax->ws_kind_host, 0u, __ATOMIC_RELAXED);
             __atomic_store_n(tax->ws_kind_host + 1, 0xFFFFFFFFu, __ATOMIC_RELAXED);
         }
-        tax->ws_kind_key_ptr = seg_off; tax->ws_kind_key_n = n_queries;
+        tax->ws_kind_key_ptr[0] = h.seg_off; tax->ws_kind_key_ptr[1] = h.bitscore; tax->ws_kind_key_ptr[2] = side;
+        tax->ws_kind_key_n[0] = h.n_queries; tax->ws_kind_key_n[1] = h.n_hits;
         return forced_kind;
     }
     const uint32_t kind = forced_kind ? forced_kind : __atomic_load_n(tax->ws_kind_host, __ATOMIC_RELAXED);
     // the queue length the table's last run reported: next to nothing -> no launch of the worklist kernel (BLU_NO_TAIL=1: always launch it)
     const uint32_t last_len = __atomic_load_n(tax->ws_kind_host + 1, __ATOMIC_RELAXED);
     static const bool never = getenv("BLU_NO_TAIL") != nullptr;
-    return kind | ((last_len <= 32u && !never) ? 4u : 0u);
+    return kind | ((last_len <= 32u && !never && !staged) ? 4u : 0u);
 }
 
 extern "C" {
@@ -77,7 +86,8 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     if (hits->packed64 && ((uintptr_t)hits->packed64 & 7u)) { set_error("packed64 records must be 8-byte aligned"); return BLU_ERR_INVALID_ARG; }
     if (hipSetDevice(tax->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", tax->device); return BLU_ERR_NO_DEVICE; }
 
-    TaxDev td{tax->d_lin, tax->d_codes, tax->d_kthr, tax->sc, tax->d_lcp8, tax->d_rmq, tax->rmq_nb, tax->d_cutvals, tax->n_cutvals, tax->n_tax, tax->dev_stride, tax->node_base, tax->max_depth, std::max<uint32_t>(tax->n_shapes, 1u)};
+    TaxDev td{tax->d_lin, tax->d_codes, tax->d_kthr, tax->sc, tax->d_lcp8, tax->d_rmq, tax->rmq_nb, tax->d_cutvals, tax->n_cutvals, tax->n_tax, tax->dev_stride, tax->node_base, tax->max_depth, std::max<uint32_t>(tax->n_shapes, 1u),
+               tax->d_wblk, tax->d_wchain, tax->d_wchain_hi, tax->wide_levels};
     if (tax->ws_capacity < hits->n_queries || !tax->ws_count) {
         // grows only when a larger table than any before arrives (first call): not graph-capturable
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
@@ -100,7 +110,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
         HitsDev hd{hits->bitscore, hits->tax_row, hits->pident, hits->pident_milli, hits->packed, hits->align_len, hits->acc_rank, hits->seg_off,
                    hits->n_hits, hits->n_queries, hits->packed64};
         return launch_consensus(td, hd, params->strategy, out, params->stream, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count,
-                                tax->ws_kind_dev, known_kind(tax, hits->seg_off, hits->n_queries));
+                                tax->ws_kind_dev, known_kind(tax, hd, false));
     }
 
     // host pointers: stage over PCIe, run, copy the records back (synchronous).  The table goes over in chunks of whole
@@ -113,8 +123,13 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     size_t chunk_rows = nh;
     {
         size_t free_b = 0, total_b = 0;
+        // slots this layout does not use are given back first (a columns call leaves slots 2..4 behind; counting them as room
+        // for a packed table's larger slot 1 made its hipMalloc fail)
+        for (int k = 0; k < 2; ++k)
+            for (int slot = 2; slot <= 4; ++slot)
+                if ((packed || wide) && tax->ws_stage[k][slot]) { (void)hipFree(tax->ws_stage[k][slot]); tax->ws_stage[k][slot] = nullptr; tax->ws_stage_bytes[k][slot] = 0; }
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            for (auto& set : tax->ws_stage_bytes) for (size_t b : set) free_b += b;   // (what the handle holds already is there to be used)
+            for (auto& set : tax->ws_stage_bytes) for (size_t b : set) free_b += b;   // (what the handle still holds is there to be reused)
             const size_t budget = free_b / 5 * 2 / row_bytes;          // two buffer sets within 80 % of what is free
             if (budget < chunk_rows) chunk_rows = budget;
         }
@@ -217,7 +232,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
                        milli ? (const uint32_t*)st.pid : nullptr, packed ? (const uint32_t*)st.pid : nullptr, (const int32_t*)st.aln,
                        (const uint32_t*)st.acc, (const uint64_t*)st.seg, cr, cq, wide ? (const uint32_t*)st.pid : nullptr};
             rc = launch_consensus(td, hd, params->strategy, (blu_result*)st.out, st.s, tax->device, tax->num_cus, tax->ws_worklist, tax->ws_count,
-                                  tax->ws_kind_dev, known_kind(tax, st.seg, cq));
+                                  tax->ws_kind_dev, known_kind(tax, hd, true));
             if (rc != BLU_OK) goto done;
             if (n_chunks > 1) HIP_TRY(hipEventRecord(kernels_done, st.s));
             HIP_TRY(hipMemcpyAsync(out + st.q0, st.out, cq * sizeof(blu_result), hipMemcpyDeviceToHost, st.s));
@@ -231,6 +246,14 @@ done:
         if (n_chunks > 1 && st.s) (void)hipStreamDestroy(st.s);
     }
     if (kernels_done) (void)hipEventDestroy(kernels_done);
+    {
+        // What the handle keeps for the next call: the buffers of a table that went over in ONE chunk, up to BLU_STAGE_KEEP_BYTES
+        // in all.  A chunked run sized its buffers from (most of) the free memory of the card: keeping those would leave GPU
+        // ingest, torch or a second handle in the same process with a nearly full device (blu_taxonomy_trim frees the rest).
+        size_t held = 0;
+        for (auto& set : tax->ws_stage_bytes) for (size_t b : set) held += b;
+        if (n_chunks > 1 || held > BLU_STAGE_KEEP_BYTES || rc != BLU_OK) (void)blu_taxonomy_trim(tax);
+    }
     return rc;
 }
 

@@ -60,7 +60,25 @@ struct TaxDev {
     uint32_t node_base;      // word of the row where the node ids start (BLU_ROW_NODE_BASE)
     uint32_t max_depth;      // longest lineage: bounds the length bits of a (possibly corrupt) row id
     uint32_t n_shapes;       // rows of codes / kthr (>= 1): bounds a (possibly corrupt) shape id
+    // Shared levels of a WIDE group (more than BLU_ROW_RUN_MAX sorted rows either side of the reference row) without the
+    // range-minimum tables.  A node of the taxonomy with at least BLU_WIDE_MIN rows is "wide"; every node that holds a wide
+    // group is wide, and so is each of its ancestors, so the wide nodes form a small tree (15 k nodes at 2.4 M taxids).
+    //   wblk[pos >> 6]    deepest wide node around each sorted position of a 64-row block: {w0 | w1 << 16, w2 | s1 << 16 | s2 << 24} —
+    //                     w0 up to offset s1, w1 up to s2, w2 after (node id + 1, 0 = none); s1 == BLU_WBLK_OVERFLOW: more than two
+    //                     changes inside the block, ask the range-minimum tables
+    //   wchain[w][16]     end (exclusive sorted position) of the ancestor at level i of wide node w - 1, i = 0 .. its own level;
+    //                     0 beyond.  Row 0 is all zeros (no wide node).
+    // The group [lo, hi] shares exactly the levels i with hi < wchain[w(lo)][i]: the nodes that hold lo AND hi are wide, hold lo,
+    // and are therefore that chain's prefix.  0.3 MB + 1 MB, hot in L2, instead of four lines of the 5 MB lcp8 / rmq tables.
+    const uint2* wblk = nullptr;       // null: no wide tables (more than 65534 wide nodes, or a wide node deeper than 32 levels)
+    const uint32_t* wchain = nullptr;  // [n_wide + 1][BLU_WCHAIN]
+    const uint32_t* wchain_hi = nullptr;   // levels 16 .. 31 of the chains, when wide_levels > 16
+    uint32_t wide_levels = 0;          // deepest wide node's level + 1
 };
+#define BLU_WIDE_MIN 128u          // rows of a node from which it is "wide" (a wide group spans at least BLU_ROW_RUN_MAX + 2 rows)
+#define BLU_WCHAIN 16u             // chain entries per table row
+#define BLU_WBLK_SHIFT 6u          // 64 sorted positions per wblk entry
+#define BLU_WBLK_OVERFLOW 0xFFu
 
 #define BLU_ROW_IV_LEVELS 20u    // levels whose neighbour run lengths sit in the row (words 1..10)
 #define BLU_ROW_RUN_MAX 127u     // a run length byte saturates here
@@ -125,6 +143,15 @@ struct blu_taxonomy {
     uint8_t* d_lcp8 = nullptr;
     uint8_t* d_rmq = nullptr;
     uint32_t rmq_nb = 0;
+    uint2* d_wblk = nullptr;                 // wide-group tables (TaxDev::wblk, wchain, wchain_hi); null = not built
+    uint32_t* d_wchain = nullptr;
+    uint32_t* d_wchain_hi = nullptr;
+    uint32_t wide_levels = 0;
+    uint32_t n_wide = 0;
+    std::vector<uint8_t> h_lcp8;             // host copies of the span tables (blu_taxonomy_shared_levels: the tests' view of them)
+    std::vector<uint8_t> h_rmq;
+    std::vector<uint2> h_wblk;
+    std::vector<uint32_t> h_wchain, h_wchain_hi;
     std::vector<uint32_t> pos_of;            // caller's tax_row -> sorted position
     std::vector<uint16_t> hint_of_pos;       // sorted position -> shape hint of the packed layout (shape id + 1, 0 = none)
     uint16_t* d_hint_of_pos = nullptr;
@@ -140,13 +167,16 @@ struct blu_taxonomy {
     mutable uint32_t* ws_worklist = nullptr;
     mutable uint32_t* ws_count = nullptr;
     mutable uint64_t ws_capacity = 0;
+    mutable uint32_t* ws_pack_flag = nullptr;        // blu_hits_pack's "a value does not fit the record" word
     // which stream kernel the handle's last table wanted (consensus_kernel.hip: blu_classify_tasks): a pinned host word the
     // device writes, its device address, and the number of run calls so far
     mutable uint32_t* ws_kind_host = nullptr;
     mutable uint32_t* ws_kind_dev = nullptr;
     mutable uint64_t ws_calls = 0;
-    mutable const void* ws_kind_key_ptr = nullptr;   // the table the remembered kind belongs to: its offsets pointer and query count
-    mutable uint64_t ws_kind_key_n = 0;
+    // the table the remembered kind and queue length belong to: the pointers of its offsets, bit-scores and side values, its query
+    // and row counts (a caching allocator hands the same offsets address to the next table of the same size: all five must agree)
+    mutable const void* ws_kind_key_ptr[3] = {nullptr, nullptr, nullptr};
+    mutable uint64_t ws_kind_key_n[2] = {0, 0};
     // Staging buffers of the host-pointer path of blu_consensus_run (two sets: a table staged in chunks is double-buffered),
     // kept with the handle and grown on demand instead of seven hipMalloc / hipFree pairs per call; [k][slot]: slot 0 bit-scores,
     // 1 side values (records, or the perc_identity column), 2 tax rows, 3 align_length, 4 accession ranks, 5 offsets, 6 records out

@@ -375,6 +375,21 @@ __device__ __forceinline__ uint32_t shared_levels(const TaxDev& t, uint32_t lo, 
     return m;
 }
 
+// Shared levels of a WIDE group from the wide-node tables (TaxDev::wblk / wchain): the deepest wide node around `lo` out of
+// its 64-row block's entry, then the number of its ancestors-or-self — one per level from 0 — whose run still holds `hi`.
+// wide_node(): 0 = none, 0xFFFFFFFF = the block has more changes than its entry holds (ask the range-minimum tables).
+__device__ __forceinline__ uint32_t wide_node(const uint2 e, const uint32_t lo) {
+    const uint32_t o = lo & ((1u << BLU_WBLK_SHIFT) - 1u), s1 = (e.y >> 16) & 0xFFu, s2 = e.y >> 24;
+    const uint32_t w = o >= s2 ? (e.y & 0xFFFFu) : (o >= s1 ? e.x >> 16 : e.x & 0xFFFFu);
+    return s1 == BLU_WBLK_OVERFLOW ? 0xFFFFFFFFu : w;
+}
+__device__ __forceinline__ uint32_t chain_count(const uint4 c0, const uint4 c1, const uint4 c2, const uint4 c3, const uint32_t hi) {
+    return (uint32_t)(c0.x > hi) + (uint32_t)(c0.y > hi) + (uint32_t)(c0.z > hi) + (uint32_t)(c0.w > hi) +
+           (uint32_t)(c1.x > hi) + (uint32_t)(c1.y > hi) + (uint32_t)(c1.z > hi) + (uint32_t)(c1.w > hi) +
+           (uint32_t)(c2.x > hi) + (uint32_t)(c2.y > hi) + (uint32_t)(c2.z > hi) + (uint32_t)(c2.w > hi) +
+           (uint32_t)(c3.x > hi) + (uint32_t)(c3.y > hi) + (uint32_t)(c3.z > hi) + (uint32_t)(c3.w > hi);
+}
+
 // ===============================================================================
 // Kernel A
 // ===============================================================================
@@ -443,6 +458,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef BLU_REF_NT
 #define BLU_REF_NT 0   // reference-row loads non-temporal (experiment)
+#endif
+#ifndef BLU_WIDE_RMQ
+#define BLU_WIDE_RMQ 0   // 1: wide groups ask the range-minimum tables as before round 4 (A/B and a test of the fallback)
 #endif
 
 // The bit-score stream of a task whose segments are all streamed goes through a per-wave LDS ring, filled by LDS-DMA
@@ -1841,6 +1859,23 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             // levels), read with eight 16-byte loads issued back to back: one memory request.  (Reading the node id
             // later, after the codes lookup, fetched the line a second time for half of the queries: the stream had
             // pushed it out of L2 in between.)
+            // Levels shared by the whole group (find_multi_taxa_consensus.rs:137-180): every row agrees with the reference row on
+            // exactly the levels all rows of the span [lo, hi] share, and the scan never looks past the shortest lineage.
+            // Seen from the reference row r that is the number of levels whose run reaches dl = r - lo rows to the left and
+            // dh = hi - r rows to the right: 20 byte compares on the row that is read anyway, exact below 127 rows either
+            // side.  A wider group takes the wide-node tables (two L2 lookups, the first requested here, IN FRONT of the
+            // reference row: vmcnt retires in issue order, so a lookup requested behind the row could not be used before the row
+            // has arrived) — or, where those do not reach, the range-minimum tables, requested together with the row.
+            const bool spread = !single && g_lo < g_hi && !BLU_X_SKIP_RUNLEN;
+            const uint32_t dl = r_row - g_lo, dh = g_hi - r_row;     // lo <= reference row <= hi
+#ifdef BLU_X_NO_WIDE
+            const bool wide = false;   // (timing only: wrong records for wide groups)
+#else
+            const bool wide = spread && (dl > BLU_ROW_RUN_MAX || dh > BLU_ROW_RUN_MAX);   // saturated run lengths: not decidable from the row
+#endif
+            const bool wide_tab = wide && t.wblk != nullptr && !BLU_WIDE_RMQ;
+            uint2 wentry = make_uint2(0u, 0u);
+            if (wide_tab) wentry = t.wblk[g_lo >> BLU_WBLK_SHIFT];
             const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
             const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
             constexpr bool NODE_RELOAD = ((BLU_NODE_RELOAD_LAYOUTS >> LAYOUT) & 1u) != 0u || (!RING && BLU_NODE_RELOAD_NORING) ||
@@ -1881,21 +1916,19 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     for (int k = 0; k < 4; ++k) ck[k] = kg[k];
                 }
             }
-            // Levels shared by the whole group (find_multi_taxa_consensus.rs:137-180): every row agrees with the reference row on
-            // exactly the levels all rows of the span [lo, hi] share, and the scan never looks past the shortest lineage.
-            // Seen from the reference row r that is the number of levels whose run reaches dl = r - lo rows to the left and
-            // dh = hi - r rows to the right: 20 byte compares on the row that is read anyway, exact below 127 rows either
-            // side.  A wider group asks the range-minimum tables, and asks them NOW: the span is known since phase 2a, so
-            // those lookups travel together with the reference row instead of after it.
-            const bool spread = !single && g_lo < g_hi && !BLU_X_SKIP_RUNLEN;
-            const uint32_t dl = r_row - g_lo, dh = g_hi - r_row;     // lo <= reference row <= hi
-#ifdef BLU_X_NO_WIDE
-            const bool wide = false;   // (timing only: wrong records for wide groups)
-#else
-            const bool wide = spread && (dl > BLU_ROW_RUN_MAX || dh > BLU_ROW_RUN_MAX);   // saturated run lengths: not decidable from the row
-#endif
             uint32_t d_tab = 0;
-            if (wide) d_tab = shared_levels(t, g_lo, g_hi);
+            if (wide_tab) {
+                // the chain of the deepest wide node around lo (row 0 of the table: no such node -> nothing shared)
+                const uint32_t wn = wide_node(wentry, g_lo);
+                const uint4* ch = reinterpret_cast<const uint4*>(t.wchain + (uint64_t)(wn == 0xFFFFFFFFu ? 0u : wn) * BLU_WCHAIN);
+                const uint4 c0 = ch[0], c1 = ch[1], c2 = ch[2], c3 = ch[3];
+                d_tab = chain_count(c0, c1, c2, c3, g_hi);
+                if (t.wide_levels > BLU_WCHAIN && d_tab == BLU_WCHAIN) {     // (deep taxonomies: levels 16 .. 31 of the chain)
+                    const uint4* cg = reinterpret_cast<const uint4*>(t.wchain_hi + (uint64_t)wn * BLU_WCHAIN);
+                    d_tab += chain_count(cg[0], cg[1], cg[2], cg[3], g_hi);
+                }
+                if (wn == 0xFFFFFFFFu) d_tab = shared_levels(t, g_lo, g_hi);
+            } else if (wide) d_tab = shared_levels(t, g_lo, g_hi);
             STAMP_DRAIN
             STAMP(4)   // reference rows arrive
             r_hdr = w[0].x;   // (requesting it back in phase 2a costs a second fetch: the line leaves L2 in between)
@@ -2125,6 +2158,13 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     // last one running, works it off itself (every other block has finished and published its entries).
     __shared__ uint32_t s_drain, s_last;
     uint32_t* const s_cnt = s_lds[0].meta;   // (the queues' lengths, for the drain below: the first wave's task table is dead by now)
+    if (no_long) {
+        // The entries this wave queued are read by the last block of THIS kernel (no kernel boundary in between): every wave makes
+        // its own stores visible at agent scope before the block's ticket — the barrier below is a workgroup-scope release and
+        // does not wait for other waves' stores to have left the CU.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();

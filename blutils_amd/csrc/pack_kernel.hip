@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void pack24_kernel(const uint32_t* __restrict_
 int check_args(const blu_taxonomy* tax, const blu_hits* c, const void* out) {
     if (!tax || !c) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
     if (c->n_hits == 0) return BLU_OK;
+    if (c->n_hits >= 0xFFFFFFFFull) { set_error("n_hits must be < 2^32 - 1 per call"); return BLU_ERR_INVALID_ARG; }   // (as blu_consensus_run; one thread per row: the grid stays below 2^31 blocks)
     if (!out || !c->tax_row || !c->align_len || !c->acc_rank || ((c->pident != nullptr) + (c->pident_milli != nullptr) != 1)) {
         set_error("blu_hits_pack needs tax_row, align_len, acc_rank and one of pident / pident_milli"); return BLU_ERR_INVALID_ARG;
     }
@@ -103,9 +104,10 @@ int blu_hits_pack(const blu_taxonomy* tax, const blu_hits* c, uint32_t* out, voi
     if ((uintptr_t)out & 15u) { set_error("packed records must be 16-byte aligned"); return BLU_ERR_INVALID_ARG; }
     if (hipSetDevice(tax->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", tax->device); return BLU_ERR_NO_DEVICE; }
     hipStream_t s = (hipStream_t)stream;
-    uint32_t* d_bad = nullptr;
+    // the "a value does not fit" word lives with the handle (allocated by the first call): no hipMalloc / hipFree per call
+    if (!tax->ws_pack_flag && hipMalloc((void**)&tax->ws_pack_flag, 64) != hipSuccess) { tax->ws_pack_flag = nullptr; set_error("hipMalloc failed"); return BLU_ERR_ALLOC; }
+    uint32_t* const d_bad = tax->ws_pack_flag;
     uint32_t bad = 0;
-    if (hipMalloc((void**)&d_bad, 4) != hipSuccess) { set_error("hipMalloc failed"); return BLU_ERR_ALLOC; }
     hipError_t e = hipMemsetAsync(d_bad, 0, 4, s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->tax_row, c->pident, c->pident_milli, c->align_len,
@@ -114,7 +116,6 @@ int blu_hits_pack(const blu_taxonomy* tax, const blu_hits* c, uint32_t* out, voi
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_bad);
     if (e != hipSuccess) { set_error("blu_hits_pack: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
     if (bad) { set_error("blu_hits_pack: a perc_identity is not an exact milli-percent value below 131.071 (use the column layouts or blu_hits_pack64)"); return BLU_ERR_INVALID_ARG; }
     return BLU_OK;

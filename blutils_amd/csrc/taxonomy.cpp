@@ -415,6 +415,81 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
             rmq[(size_t)k * nb + j] = std::min(rmq[(size_t)(k - 1) * nb + j], rmq[(size_t)(k - 1) * nb + j + (1u << (k - 1))]);
     tax->rmq_nb = nb;
 
+    // ---- wide-group tables (TaxDev::wblk / wchain): the nodes with at least BLU_WIDE_MIN rows, in preorder --------------
+    // A node at level j is a maximal run of sorted rows that share levels 0..j (and have that many).  Runs are closed when a
+    // row shares fewer levels with its predecessor; the wide ones are kept as {level, start, end}.
+    struct WideNode { uint32_t level, s, e, parent; };
+    std::vector<WideNode> wide;
+    std::vector<uint2> wblk;
+    std::vector<uint32_t> wchain, wchain_hi;
+    uint32_t wide_levels = 0;
+    bool wide_ok = true;
+    {
+        std::vector<uint32_t> open_s(D, 0);
+        std::vector<uint8_t> open_on(D, 0);
+        auto close_from = [&](uint32_t j0, uint32_t upto, uint32_t end) {
+            for (uint32_t j = j0; j < upto; ++j) {
+                if (open_on[j] && end - open_s[j] >= BLU_WIDE_MIN) wide.push_back({j, open_s[j], end, 0u});
+                open_on[j] = 0;
+            }
+        };
+        uint32_t prev_len = 0;
+        for (uint64_t r = 0; r < n; ++r) {
+            const uint32_t len = lin_sorted[(size_t)r * stride] & 0xFF;
+            const uint32_t shared = r > 0 ? std::min<uint32_t>(lcp8[r - 1], std::min(len, prev_len)) : 0;
+            close_from(shared, prev_len, (uint32_t)r);
+            for (uint32_t j = shared; j < len; ++j) { open_s[j] = (uint32_t)r; open_on[j] = 1; }
+            prev_len = len;
+        }
+        close_from(0, prev_len, (uint32_t)n);
+        // preorder: by start, then by level (an ancestor starts no later than its descendants and is shallower)
+        std::sort(wide.begin(), wide.end(), [](const WideNode& a, const WideNode& b) { return a.s != b.s ? a.s < b.s : a.level < b.level; });
+        for (const auto& w : wide) wide_levels = std::max(wide_levels, w.level + 1);
+        if (wide.size() >= 65535u || wide_levels > 2 * BLU_WCHAIN) wide_ok = false;
+    }
+    if (wide_ok) {
+        // deepest wide node per position (id + 1), parents from a stack of the open ancestors
+        std::vector<uint16_t> deepest(std::max<uint64_t>(n, 1), 0);
+        std::vector<uint32_t> stack;
+        wchain.assign((wide.size() + 1) * BLU_WCHAIN, 0u);
+        if (wide_levels > BLU_WCHAIN) wchain_hi.assign((wide.size() + 1) * BLU_WCHAIN, 0u);
+        for (size_t w = 0; w < wide.size(); ++w) {
+            while (!stack.empty() && wide[stack.back()].e <= wide[w].s) stack.pop_back();
+            wide[w].parent = stack.empty() ? 0xFFFFFFFFu : stack.back();
+            stack.push_back((uint32_t)w);
+            // the chain of w: its parent's, plus its own end at its own level (levels in between cannot be missing: every
+            // ancestor of a wide node is wide)
+            uint32_t* ch = &wchain[(w + 1) * BLU_WCHAIN];
+            uint32_t* ch_hi = wchain_hi.empty() ? nullptr : &wchain_hi[(w + 1) * BLU_WCHAIN];
+            if (wide[w].parent != 0xFFFFFFFFu) {
+                memcpy(ch, &wchain[((size_t)wide[w].parent + 1) * BLU_WCHAIN], BLU_WCHAIN * sizeof(uint32_t));
+                if (ch_hi) memcpy(ch_hi, &wchain_hi[((size_t)wide[w].parent + 1) * BLU_WCHAIN], BLU_WCHAIN * sizeof(uint32_t));
+            }
+            const uint32_t lv = wide[w].level;
+            if (lv < BLU_WCHAIN) ch[lv] = wide[w].e; else ch_hi[lv - BLU_WCHAIN] = wide[w].e;
+            for (uint32_t p = wide[w].s; p < wide[w].e; ++p) deepest[p] = (uint16_t)(w + 1);   // (preorder: deeper nodes overwrite)
+        }
+        const uint64_t nblk = (n >> BLU_WBLK_SHIFT) + 1;
+        wblk.assign(nblk, make_uint2(0u, 0u));
+        for (uint64_t b = 0; b < nblk; ++b) {
+            const uint64_t p0 = b << BLU_WBLK_SHIFT, p1 = std::min<uint64_t>(n, p0 + (1u << BLU_WBLK_SHIFT));
+            uint32_t w[3] = {p0 < n ? deepest[p0] : 0u, 0u, 0u}, sp[2] = {1u << BLU_WBLK_SHIFT, 1u << BLU_WBLK_SHIFT};
+            uint32_t changes = 0;
+            for (uint64_t p = p0 + 1; p < p1; ++p)
+                if (deepest[p] != deepest[p - 1]) {
+                    if (changes < 2) { sp[changes] = (uint32_t)(p - p0); w[changes + 1] = deepest[p]; }
+                    ++changes;
+                }
+            if (changes > 2) wblk[b] = make_uint2(0u, (uint32_t)BLU_WBLK_OVERFLOW << 16);
+            else wblk[b] = make_uint2(w[0] | (w[1] << 16), w[2] | (sp[0] << 16) | (sp[1] << 24));
+        }
+    }
+    tax->n_wide = (uint32_t)wide.size();
+    tax->wide_levels = wide_ok ? wide_levels : 0;
+    tax->h_lcp8 = lcp8;
+    tax->h_rmq = rmq;
+    if (wide_ok) { tax->h_wblk = wblk; tax->h_wchain = wchain; tax->h_wchain_hi = wchain_hi; }
+
     if (device >= 0) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -440,6 +515,16 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         if (e == hipSuccess) e = hipMemcpy(tax->d_lcp8, lcp8.data(), lcp8.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_rmq, rmq.data(), rmq.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(tax->d_cutvals, cutvals.data(), b_cut, hipMemcpyHostToDevice);
+        if (wide_ok && !wblk.empty()) {
+            if (e == hipSuccess) e = hipMalloc((void**)&tax->d_wblk, wblk.size() * sizeof(uint2));
+            if (e == hipSuccess) e = hipMemcpy(tax->d_wblk, wblk.data(), wblk.size() * sizeof(uint2), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void**)&tax->d_wchain, wchain.size() * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemcpy(tax->d_wchain, wchain.data(), wchain.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (!wchain_hi.empty()) {
+                if (e == hipSuccess) e = hipMalloc((void**)&tax->d_wchain_hi, wchain_hi.size() * sizeof(uint32_t));
+                if (e == hipSuccess) e = hipMemcpy(tax->d_wchain_hi, wchain_hi.data(), wchain_hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            }
+        }
         if (e == hipSuccess) e = hipMalloc((void**)&tax->d_hint_of_pos, tax->hint_of_pos.size() * sizeof(uint16_t));
         if (e == hipSuccess) e = hipMemcpy(tax->d_hint_of_pos, tax->hint_of_pos.data(), tax->hint_of_pos.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -447,7 +532,8 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
             blu_taxonomy_destroy(tax);
             return BLU_ERR_HIP;
         }
-        tax->device_bytes = b_lin + lcp8.size() + rmq.size() + b_cut + 2 * b_codes + tax->hint_of_pos.size() * sizeof(uint16_t);
+        tax->device_bytes = b_lin + lcp8.size() + rmq.size() + b_cut + 2 * b_codes + tax->hint_of_pos.size() * sizeof(uint16_t) +
+                            (tax->d_wblk ? wblk.size() * sizeof(uint2) + (wchain.size() + wchain_hi.size()) * sizeof(uint32_t) : 0);
     }
     *out = tax;
     return BLU_OK;
@@ -460,12 +546,16 @@ void blu_taxonomy_destroy(blu_taxonomy* tax) {
         if (tax->d_lin) (void)hipFree(tax->d_lin);
         if (tax->d_lcp8) (void)hipFree(tax->d_lcp8);
         if (tax->d_rmq) (void)hipFree(tax->d_rmq);
+        if (tax->d_wblk) (void)hipFree(tax->d_wblk);
+        if (tax->d_wchain) (void)hipFree(tax->d_wchain);
+        if (tax->d_wchain_hi) (void)hipFree(tax->d_wchain_hi);
         if (tax->d_cutvals) (void)hipFree(tax->d_cutvals);
         if (tax->d_codes) (void)hipFree(tax->d_codes);
         if (tax->d_kthr) (void)hipFree(tax->d_kthr);
         if (tax->d_hint_of_pos) (void)hipFree(tax->d_hint_of_pos);
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
         if (tax->ws_count) (void)hipFree(tax->ws_count);
+        if (tax->ws_pack_flag) (void)hipFree(tax->ws_pack_flag);
         if (tax->ws_kind_host) (void)hipHostFree(tax->ws_kind_host);
         for (auto& set : tax->ws_stage) for (void* p : set) if (p) (void)hipFree(p);
     }
@@ -504,6 +594,62 @@ int blu_taxonomy_lookup(const blu_taxonomy* tax, const int64_t* taxid, uint64_t 
         auto it = tax->taxid_row.find(taxid[i]);
         out_row[i] = it == tax->taxid_row.end() ? BLU_UNMATCHED_TAXID : tax->pos_of[it->second];
     }
+    return BLU_OK;
+}
+
+int blu_taxonomy_shared_levels(const blu_taxonomy* tax, uint32_t lo, uint32_t hi, uint32_t* by_scan, uint32_t* by_tables, int32_t* via) {
+    if (!tax || lo > hi || hi >= tax->n_tax) { set_error("blu_taxonomy_shared_levels: need lo <= hi < n_tax"); return BLU_ERR_INVALID_ARG; }
+    const std::vector<uint8_t>& lcp = tax->h_lcp8;
+    if (by_scan) {
+        uint32_t m = 0xFFu;
+        for (uint32_t i = lo; i < hi; ++i) m = std::min<uint32_t>(m, lcp[i]);
+        *by_scan = lo == hi ? (tax->h_lin[(size_t)tax->order[lo] * tax->stride] & 0xFFu) : m;
+    }
+    if (by_tables || via) {
+        uint32_t r = 0;
+        int32_t v = 0;
+        if (lo == hi) r = tax->h_lin[(size_t)tax->order[lo] * tax->stride] & 0xFFu;
+        else if (hi - lo >= BLU_WIDE_MIN && !tax->h_wblk.empty()) {
+            // what phase 2c of the stream kernel does (consensus_kernel.hip: wide_node, chain_count)
+            const uint2 e = tax->h_wblk[lo >> BLU_WBLK_SHIFT];
+            const uint32_t o = lo & ((1u << BLU_WBLK_SHIFT) - 1u), s1 = (e.y >> 16) & 0xFFu, s2 = e.y >> 24;
+            if (s1 != BLU_WBLK_OVERFLOW) {
+                const uint32_t w = o >= s2 ? (e.y & 0xFFFFu) : (o >= s1 ? e.x >> 16 : e.x & 0xFFFFu);
+                for (uint32_t i = 0; i < BLU_WCHAIN; ++i) r += tax->h_wchain[(size_t)w * BLU_WCHAIN + i] > hi;
+                if (r == BLU_WCHAIN && !tax->h_wchain_hi.empty())
+                    for (uint32_t i = 0; i < BLU_WCHAIN; ++i) r += tax->h_wchain_hi[(size_t)w * BLU_WCHAIN + i] > hi;
+                v = 1;
+            }
+        }
+        if (lo != hi && v == 0) {
+            // the sparse table over 16-entry blocks of lcp8 (consensus_kernel.hip: shared_levels)
+            const uint32_t b0 = (lo + 15) >> 4, b1 = hi >> 4;
+            uint32_t m = 0xFFu;
+            if (b0 > b1) { for (uint32_t i = lo; i < hi; ++i) m = std::min<uint32_t>(m, lcp[i]); }
+            else {
+                for (uint32_t i = lo; i < (b0 << 4); ++i) m = std::min<uint32_t>(m, lcp[i]);
+                for (uint32_t i = b1 << 4; i < hi; ++i) m = std::min<uint32_t>(m, lcp[i]);
+                if (b0 < b1) {
+                    uint32_t k = 0;
+                    while ((2u << k) <= b1 - b0) ++k;
+                    m = std::min<uint32_t>(m, tax->h_rmq[(size_t)k * tax->rmq_nb + b0]);
+                    m = std::min<uint32_t>(m, tax->h_rmq[(size_t)k * tax->rmq_nb + b1 - (1u << k)]);
+                }
+            }
+            r = m;
+        }
+        if (by_tables) *by_tables = r;
+        if (via) *via = v;
+    }
+    return BLU_OK;
+}
+
+int blu_taxonomy_trim(const blu_taxonomy* tax) {
+    if (!tax) { set_error("null argument"); return BLU_ERR_INVALID_ARG; }
+    if (tax->device < 0) return BLU_OK;
+    if (hipSetDevice(tax->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", tax->device); return BLU_ERR_NO_DEVICE; }
+    for (auto& set : tax->ws_stage) for (void*& p : set) if (p) { (void)hipFree(p); p = nullptr; }
+    for (auto& set : tax->ws_stage_bytes) for (size_t& b : set) b = 0;
     return BLU_OK;
 }
 

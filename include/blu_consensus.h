@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BLU_ABI_VERSION 4u
+#define BLU_ABI_VERSION 5u
 #define BLU_UNMATCHED_TAXID 0xFFFFFFFFu /* hit whose subject_taxid is not in the taxonomy (left join miss, mod.rs:72-76) */
 #define BLU_MAX_DEPTH 64u               /* level_mask is 64 bits wide */
 #define BLU_ROW_BITS 25u                /* engine row id = sorted position | lineage length << 25: at most 2^25 taxids */
@@ -201,6 +201,17 @@ int blu_taxonomy_lookup(const blu_taxonomy* tax, const int64_t* taxid, uint64_t 
 /* desc row index -> engine row id for every row of the table (out_map[n_tax]); inverse in out_inverse[n_tax]
  * (either may be NULL).  For callers that already hold desc row indices. */
 int blu_taxonomy_row_map(const blu_taxonomy* tax, uint32_t* out_map, uint32_t* out_inverse);
+/* (ABI v5, introspection) Number of leading lineage levels shared by ALL rows at sorted positions lo..hi (the low BLU_ROW_BITS
+ * bits of engine row ids; lo <= hi < n_tax) — what the per-level scan of find_multi_taxa_consensus.rs:137-180 finds for a
+ * top group spanning those positions, before the clamp to the shortest lineage.  *by_scan: from the adjacent-row prefix
+ * lengths, one by one; *by_tables: what the engine's tables give (the wide-node chains for spans of 128 rows and more,
+ * the range-minimum tables otherwise and where the chains do not reach; *via = 1 chains, 0 range minimum).  The two
+ * must agree; any pointer may be NULL.  Host only, no device needed. */
+int blu_taxonomy_shared_levels(const blu_taxonomy* tax, uint32_t lo, uint32_t hi, uint32_t* by_scan, uint32_t* by_tables, int32_t* via);
+/* (ABI v5) Frees the device buffers the handle keeps from call to call for the host-pointer path of blu_consensus_run
+ * (the staged columns and records of the largest table so far).  The handle stays valid; the next host-pointer call
+ * allocates what it needs again.  No run on the handle may be in flight. */
+int blu_taxonomy_trim(const blu_taxonomy* tax);
 
 /* The hot path: one blu_result per query.  `out` has n_queries records, on the
  * device when hits->on_device, else on the host.  Asynchronous on

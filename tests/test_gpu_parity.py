@@ -197,15 +197,17 @@ def _intern_lineages(lineages):
     return (np.array(off, np.uint64), np.array(node, np.uint32), np.array(rk, np.uint16), ranks, inv)
 
 
-@pytest.mark.parametrize("strategy", ["relaxed", "cautious"])
-def test_golden_vectors_through_the_gpu(golden_dir, strategy):
+@pytest.mark.parametrize("strategy,reverse", [("relaxed", False), ("cautious", False), ("relaxed", True), ("cautious", True)])
+def test_golden_vectors_through_the_gpu(golden_dir, strategy, reverse):
     """The reference's golden output (zymo mock, 253 distinct results = 2283 queries) and the docs worked
-    example, re-synthesised by the §8c recipe, interned, and run through the HIP path."""
+    example, re-synthesised by the §8c recipe (align_lengths ascending in each bean's listed accession order, so that the
+    golden's own accession order is what the 4-key sort must produce; hit rows in the recipe's file order and reversed),
+    interned, and run through the HIP path."""
     with gzip.open(os.path.join(golden_dir, "zymo_mock_distilled.json.gz"), "rt") as f:
         zymo = json.load(f)
     doc = json.load(open(os.path.join(golden_dir, "docs_worked_example.json")))
     taxa = [c["taxon"] for c in zymo["cases"]] + [r["taxon"] for r in doc["results"]]
-    tab = table_from_taxa(taxa)
+    tab = table_from_taxa(taxa, reverse_file_order=reverse)
     off, node, rk, ranks, inv = _intern_lineages(tab.lineages)
     t = engine.Taxonomy(off, node, rk, ranks, taxon="bacteria", device=0)
     acc_sorted = sorted(range(len(tab.accessions)), key=lambda i: tab.accessions[i].encode())
@@ -234,6 +236,9 @@ def test_golden_vectors_through_the_gpu(golden_dir, strategy):
             mar = t.rank_name(codes[mal], serde=bool(isdef[mal]))
         o = faithful[q]["taxon"]
         assert mar == o["maxAllowedRank"] and bool(rec["flags"] & 1) == o["mutated"], (q, mar, o["maxAllowedRank"])
+        # the reference row the engine picked is the one the faithful oracle's sort picked: its accession leads (Cautious) or
+        # ends (Relaxed) the sorted list the beans were folded from
+        assert o["percIdentity"] == float(tab.pident[row]) and tab.accessions[int(tab.acc_idx[row])] in {a for b in o["consensusBeans"] for a in b["accessions"]}
         if q >= len(zymo["cases"]) and strategy == doc["strategy"]:
             assert mar == exp["maxAllowedRank"] and bool(rec["flags"] & 1) == exp["mutated"]   # docs example: all fields
 

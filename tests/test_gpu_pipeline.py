@@ -268,7 +268,8 @@ def test_golden_taxon_objects_leave_the_product_writer_byte_for_byte(tmp_path, g
             taxid = lineages.setdefault(bean["taxonomy"], 1000 + len(lineages))
             for k in range(int(bean["occurrences"])):
                 acc = bean["accessions"][min(k, len(bean["accessions"]) - 1)]
-                rows.append(f"case{i:04d}\t{acc}\t{taxid}\t{t['percIdentity']:.3f}\t400\t0\t0\t1\t400\t1\t400\t1e-50\t{int(t['bitScore'])}")
+                # (align_length ascending in the bean's listed order: tests/golden_recipe.py — the golden's accession order is then the sort's)
+                rows.append(f"case{i:04d}\t{acc}\t{taxid}\t{t['percIdentity']:.3f}\t{400 + k}\t0\t0\t1\t400\t1\t400\t1e-50\t{int(t['bitScore'])}")
     (tmp_path / "b.tsv").write_text("\n".join(rows) + "\n")
     (tmp_path / "t.json").write_text(json.dumps({"blutilsVersion": "7.1.3", "sourceDatabase": "golden", "taxonomies": [
         {"taxid": v, "rank": "", "numericLineage": k, "textLineage": k, "accessions": []} for k, v in lineages.items()]}))

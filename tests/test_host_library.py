@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     L = N.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.blu_abi_version() == 4
+    assert L.blu_abi_version() == 5
     hdr2 = open(os.path.join(ROOT, "include", "blu_pipeline.h")).read()
     declared2 = set(re.findall(r"\b(blu_[a-z0-9_]+)\s*\(", hdr2))
     assert declared2 == set(N.PIPELINE_EXPORTS)
@@ -283,3 +283,29 @@ def test_worklist_queues_fit_the_buffer_the_library_allocates():
             tasks_of_queue = len(range(s_, n_tasks, 64))
             assert tasks_of_queue * 64 <= cap
         assert 64 * cap <= nq + 8192
+
+
+def test_wide_node_tables_agree_with_the_adjacent_row_scan():
+    """Levels shared by a span of sorted rows: the wide-node chains (spans of 128 rows and more, what phase 2c of the stream
+    kernel reads) and the range-minimum tables must both give what a row-by-row scan of the adjacent-row prefix lengths gives
+    (find_multi_taxa_consensus.rs:137-180 seen in sorted order)."""
+    import ctypes as C
+    from blutils_amd import synth
+    rng = np.random.default_rng(5)
+    for n, deep in ((30000, False), (30000, True), (300, False), (129, True)):
+        tx = synth.make_taxonomy(n, 77 + n, deep=deep)
+        t = engine.Taxonomy(tx.lin_off, tx.lin_node, tx.lin_rank, tx.rank_names, taxon="bacteria", device=-1)
+        L = N.lib()
+        scan, tab, via = C.c_uint32(), C.c_uint32(), C.c_int32()
+        n_chain = 0
+        # every span width class: narrow, just wide, a few blocks, most of the table; spans that start / end on block edges
+        los = np.concatenate([rng.integers(0, n, 3000), np.arange(0, min(n, 400)), (np.arange(0, n, 64))[:400], np.maximum(np.arange(0, n, 64) - 1, 0)[:400]])
+        for lo in los:
+            for w in (0, 1, 5, 127, 128, 129, 200, 1000, int(rng.integers(1, n))):
+                hi = min(n - 1, int(lo) + w)
+                assert L.blu_taxonomy_shared_levels(t.handle, int(lo), hi, C.byref(scan), C.byref(tab), C.byref(via)) == N.BLU_OK
+                assert scan.value == tab.value, (n, deep, int(lo), hi, scan.value, tab.value, via.value)
+                n_chain += via.value
+        if n >= 30000:
+            assert n_chain > 1000          # the chains, not only the fallback, were exercised
+        t.close()
