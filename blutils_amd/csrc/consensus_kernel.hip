@@ -220,6 +220,12 @@ __device__ __forceinline__ uint32_t wl_capacity(uint64_t n_queries) {
     const uint64_t n_tasks = (n_queries + WAVE - 1) / WAVE;
     return (uint32_t)((n_tasks + WL_QUEUES - 1) / WL_QUEUES) * WAVE;
 }
+// A query goes to its task's queue: the slot from the queue's counter (agent-scope atomic), the entry as a write-through
+// (sc1) store — the entries may be read by the last block of the SAME kernel (its in-kernel drain, no kernel boundary in between),
+// which loads them with sc1 loads (wl_entry) after every wave has waited for its own stores (end of the stream kernel).
+__device__ __forceinline__ void wl_push(uint32_t* const wl_q, uint32_t* const wl_cnt, const uint32_t q) {
+    __hip_atomic_store(wl_q + atomicAdd(wl_cnt, 1u), q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // entry wi of the queues taken one after the other (incl: inclusive prefix sums of their lengths, lane = queue)
 __device__ __forceinline__ uint32_t wl_entry(const uint32_t* __restrict__ worklist, const uint32_t cap, const uint32_t incl, const uint32_t wi) {
     const uint32_t sub = (uint32_t)__builtin_popcountll(__ballot(incl <= wi));
@@ -390,6 +396,54 @@ __device__ __forceinline__ uint32_t chain_count(const uint4 c0, const uint4 c1, 
            (uint32_t)(c3.x > hi) + (uint32_t)(c3.y > hi) + (uint32_t)(c3.z > hi) + (uint32_t)(c3.w > hi);
 }
 
+// Which of a lane's N rows tie on the query's top score, row 0 in the top bit of the N-bit mask: mask = 2 mask + (b == M),
+// four rows per group — four compares into scalar pairs, then four add-with-carry (the compare's lane mask is the carry in).
+// Two vector instructions per row; as C++ ((mask << 1) | (b == M)) hipcc emits compare, select, or, shift — 3.5 per row — and the
+// scan is a third of the stream kernel's vector instructions.  (gfx950: a VALU read of a scalar pair needs two wait states
+// after the VALU write: the three instructions between a compare and its add cover them.)
+#ifndef BLU_ADDC_MASK
+#define BLU_ADDC_MASK 1
+#endif
+template <uint32_t N>
+__device__ __forceinline__ uint32_t tie_mask(const int (&b)[N], const int M) {
+    static_assert(N % 8u == 0u, "two half masks, four rows per group each");
+#if BLU_ADDC_MASK
+    // two accumulators (rows 0 .. N/2 - 1 and N/2 .. N - 1) so that consecutive adds do not depend on each other
+    constexpr uint32_t H = N / 2u;
+    uint32_t ma = 0, mb = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < H; i += 4) {
+        uint64_t s0, s1, s2, s3, s4, s5, s6, s7, j;
+        asm("v_cmp_eq_u32_e64 %[s0], %[a0], %[M]\n\t"
+            "v_cmp_eq_u32_e64 %[s4], %[b0], %[M]\n\t"
+            "v_cmp_eq_u32_e64 %[s1], %[a1], %[M]\n\t"
+            "v_cmp_eq_u32_e64 %[s5], %[b1], %[M]\n\t"
+            "v_cmp_eq_u32_e64 %[s2], %[a2], %[M]\n\t"
+            "v_cmp_eq_u32_e64 %[s6], %[b2], %[M]\n\t"
+            "v_cmp_eq_u32_e64 %[s3], %[a3], %[M]\n\t"
+            "v_cmp_eq_u32_e64 %[s7], %[b3], %[M]\n\t"
+            "v_addc_co_u32_e64 %[ma], %[j], %[ma], %[ma], %[s0]\n\t"
+            "v_addc_co_u32_e64 %[mb], %[j], %[mb], %[mb], %[s4]\n\t"
+            "v_addc_co_u32_e64 %[ma], %[j], %[ma], %[ma], %[s1]\n\t"
+            "v_addc_co_u32_e64 %[mb], %[j], %[mb], %[mb], %[s5]\n\t"
+            "v_addc_co_u32_e64 %[ma], %[j], %[ma], %[ma], %[s2]\n\t"
+            "v_addc_co_u32_e64 %[mb], %[j], %[mb], %[mb], %[s6]\n\t"
+            "v_addc_co_u32_e64 %[ma], %[j], %[ma], %[ma], %[s3]\n\t"
+            "v_addc_co_u32_e64 %[mb], %[j], %[mb], %[mb], %[s7]"
+            : [ma] "+v"(ma), [mb] "+v"(mb), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [s5] "=&s"(s5),
+              [s6] "=&s"(s6), [s7] "=&s"(s7), [j] "=&s"(j)
+            : [a0] "v"(b[i]), [a1] "v"(b[i + 1]), [a2] "v"(b[i + 2]), [a3] "v"(b[i + 3]), [b0] "v"(b[H + i]), [b1] "v"(b[H + i + 1]),
+              [b2] "v"(b[H + i + 2]), [b3] "v"(b[H + i + 3]), [M] "v"(M));
+    }
+    return (ma << H) | mb;
+#else
+    uint32_t mask = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < N; ++i) mask = (mask << 1) | (uint32_t)(b[i] == M);
+    return mask;
+#endif
+}
+
 // ===============================================================================
 // Kernel A
 // ===============================================================================
@@ -478,7 +532,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define RING_PAD 32u              // >= rows one lane scans in a step
 #define RING_CHUNKS (RING_ROWS / 256u)
 #define RING_MASK (RING_ROWS - 1u)
-static_assert((RING_ROWS & RING_MASK) == 0 && RING_ROWS >= 2048u, "ring size");
+static_assert((RING_ROWS & RING_MASK) == 0 && RING_ROWS >= 1024u, "ring size");
 // A lane of a ring step scans RPL = 16 or 32 consecutive rows (16 for tasks of short segments, 32 otherwise: half as many
 // steps per task).  Lane descriptor in the list: top-row mask | first row (13 bits) | position / RPL (3 bits) — one word with
 // the mask (top-aligned) is the first word of the list slot, the rest the second (the first row can be far into a task that
@@ -571,10 +625,35 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     const int lane = lane_id();
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     WaveLds<!PID32, RING>& L = s_lds[wib];
-    const uint64_t n_tasks = (h.n_queries + WAVE - 1) / WAVE;
     const uint32_t wl_cap = wl_capacity(h.n_queries);
-    const uint64_t wave = (uint64_t)blockIdx.x * WAVES_T + wib;
-    const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_T;
+    // (task arithmetic in 32 bits: the ABI keeps n_queries below 2^32 — worklist entries are 32-bit query ids — and every
+    // kernel-lifetime scalar of this kernel costs a register it does not have)
+    const uint32_t n_q32 = (uint32_t)h.n_queries;
+    const uint32_t wave = blockIdx.x * WAVES_T + (uint32_t)wib;
+    const uint32_t n_waves = gridDim.x * WAVES_T;
+    // Tasks: 64 consecutive queries each while there is a whole round of them (one task per wave of the grid); the queries left
+    // after the last whole round — up to a round's worth — are dealt to ALL waves in equal pieces of `tail_q` queries (a
+    // multiple of 8, at least 16) instead of 64-query tasks for some waves and nothing for the others: the kernel ends when
+    // the slowest wave does, and a piece costs less than a task.  (C4 slice, 1.25 M queries: 6 whole rounds + 1099 tasks
+    // became 6 rounds + 3072 pieces of 24 queries; C2, 100 k queries, less than one round: 1563 tasks on 131 CUs became 2500
+    // pieces of 40 on all CUs.)
+#ifndef BLU_TAIL_SPLIT
+#define BLU_TAIL_SPLIT 1
+#endif
+    const uint32_t n_tasks64 = n_q32 / WAVE + ((n_q32 % WAVE) != 0u ? 1u : 0u);
+    const uint32_t t_full = BLU_TAIL_SPLIT ? n_tasks64 / n_waves * n_waves : n_tasks64;   // tasks of the whole rounds
+    const uint32_t q_full = t_full == n_tasks64 ? n_q32 : t_full * WAVE;
+    uint32_t tail_q = WAVE;
+    if (BLU_TAIL_SPLIT) {
+        tail_q = (((n_q32 - q_full) + n_waves - 1u) / n_waves + 7u) / 8u * 8u;   // (at most 64: the tail is less than a round)
+        tail_q = tail_q < 16u ? 16u : (tail_q > WAVE ? WAVE : tail_q);
+    }
+    const uint32_t n_tasks = t_full + ((n_q32 - q_full) + tail_q - 1u) / tail_q;
+    auto task_q0 = [&](const uint32_t tk) { return tk < t_full ? tk * WAVE : q_full + (tk - t_full) * tail_q; };
+    auto task_nq = [&](const uint32_t tk) {
+        const uint32_t left = n_q32 - task_q0(tk), cap = tk < t_full ? (uint32_t)WAVE : tail_q;
+        return left < cap ? left : cap;
+    };
 
     // ---- the bit-score ring of this wave (see WaveLds).  The table's rows are numbered v = row + mis, where mis (0..3)
     // makes v = 0 fall on a 16-byte boundary of the column; chunk c = rows 256 c .. 256 c + 255 lands in ring slot
@@ -584,7 +663,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     const uint64_t v_total = h.n_hits + mis;
     uint32_t ring_head = 0, ring_landed = 0, ring_tail = 0;   // chunk ids: next to request / all before it have landed / first still needed
     uint32_t ring_c0 = 0, ring_end = 0;                        // chunk the DMA descriptor is based at / end of the task's chunks
-    uint64_t pref_task = ~0ull;                                // task whose first chunks were requested ahead
+    uint32_t pref_task = 0xFFFFFFFFu;                          // task whose first chunks were requested ahead
     // The DMA is issued as inline assembly (m0 = LDS address of the slot; buffer_load_dwordx4 ... lds) rather than through
     // __builtin_amdgcn_raw_ptr_buffer_load_lds: with the builtin hipcc puts an s_waitcnt vmcnt(0) in front of every LDS
     // read that follows (any LDS access may alias a pending LDS-DMA in its book-keeping), which drains the requests this
@@ -606,6 +685,34 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen" RING_DMA_MOD " lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs) : "memory");
     };
+    // chunks head .. lim - 1 (lim > head; ring numbering = column numbering) in one go: the loop is inside the asm statement —
+    // seven scalar instructions and one vector add per chunk where the C++ loop around ring_dma cost nineteen (m0 saved and
+    // restored per chunk, the slot address from scratch, the loop's own compares): the requests are a quarter of the stream
+    // kernel's scalar instructions.  (The slot-address add into m0 is followed by the counter increment: the wait state an
+    // LDS-DMA needs after a write of m0.)
+#ifndef BLU_DMA_RUN
+#define BLU_DMA_RUN 1
+#endif
+    auto ring_dma_run = [&](const u32x4 rs, const uint32_t c0, uint32_t head, const uint32_t lim) {
+#if BLU_DMA_RUN
+        uint32_t voff = (head - c0) * 1024u + (uint32_t)lane * 16u, keep, t;
+        asm volatile("s_mov_b32 %[keep], m0\n"
+                     "1:\n\t"
+                     "s_and_b32 %[t], %[head], %[cm]\n\t"
+                     "s_lshl_b32 %[t], %[t], 10\n\t"
+                     "s_add_u32 m0, %[t], %[base]\n\t"
+                     "s_add_u32 %[head], %[head], 1\n\t"
+                     "buffer_load_dwordx4 %[voff], %[rs], 0 offen" RING_DMA_MOD " lds\n\t"
+                     "v_add_u32 %[voff], 0x400, %[voff]\n\t"
+                     "s_cmp_lt_u32 %[head], %[lim]\n\t"
+                     "s_cbranch_scc1 1b\n\t"
+                     "s_mov_b32 m0, %[keep]"
+                     : [keep] "=&s"(keep), [t] "=&s"(t), [head] "+s"(head), [voff] "+v"(voff)
+                     : [cm] "n"(RING_CHUNKS - 1u), [base] "s"(ring_lds), [rs] "s"(rs), [lim] "s"(lim) : "memory", "scc");
+#else
+        for (; head < lim; ++head) ring_dma(rs, c0, head, head);
+#endif
+    };
 
     // The offsets of a task are requested one task ahead (lane i: the row range of query q0 + i), so that their round
     // trip is never on the critical path and the next task's first chunks can be requested while this one finishes.
@@ -613,11 +720,11 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     // all row arithmetic in 32 bits.  A corrupt table with high words set reads as some other in-range table: clamped like
     // any other, nothing faults.)
     const uint32_t n_hits32 = (uint32_t)h.n_hits;
-    auto load_seg = [&](const uint64_t tk, uint32_t& o, uint32_t& e) {
+    auto load_seg = [&](const uint32_t tk, uint32_t& o, uint32_t& e) {
         o = 0; e = 0;
         if (tk < n_tasks) {
-            const uint64_t q = tk * WAVE + (uint32_t)lane;
-            if (q < h.n_queries) {
+            const uint64_t q = (uint64_t)task_q0(tk) + (uint32_t)lane;
+            if ((uint32_t)lane < task_nq(tk)) {   // (lanes past the task's queries hold an empty segment)
                 const uint32_t* lo32 = reinterpret_cast<const uint32_t*>(h.seg_off + q);
                 o = lo32[0]; e = lo32[2];
             }
@@ -627,17 +734,19 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     load_seg(wave, nx_off, nx_end);
     STAMP_DECL
 
-    for (uint64_t task = wave; task < n_tasks; task += n_waves) {
-        const uint64_t q0 = task * WAVE;
-        const uint32_t nq = (uint32_t)((h.n_queries - q0) < WAVE ? (h.n_queries - q0) : WAVE);
-        // the worklist queue this task appends to
-        uint32_t* const wl_cnt = work_count + WL_BASE + ((uint32_t)task & (WL_QUEUES - 1u)) * WL_STRIDE;
-        uint32_t* const wl_q = worklist + (uint64_t)((uint32_t)task & (WL_QUEUES - 1u)) * wl_cap;
+    for (uint32_t task = wave; task < n_tasks; task += n_waves) {
+        const uint64_t q0 = task_q0(task);
+        const uint32_t nq = task_nq(task);
+        // the worklist queue this task appends to: by the 64-query block its first query lies in, so that a queue receives what
+        // wl_capacity() sized it for whether the tail was cut into pieces or not
+        const uint32_t wl_sel = (uint32_t)(q0 / WAVE) & (WL_QUEUES - 1u);
+        uint32_t* const wl_cnt = work_count + WL_BASE + wl_sel * WL_STRIDE;
+        uint32_t* const wl_q = worklist + (uint64_t)wl_sel * wl_cap;
         // lane i holds the row range of query q0 + i
         uint32_t my_off = nx_off, my_end = nx_end;
         if (my_end > n_hits32) my_end = n_hits32;   // defend the column reads against a corrupt offset table
         if (my_off > my_end) my_off = my_end;
-        const uint64_t next_task = task + n_waves;
+        const uint32_t next_task = task + n_waves;
         load_seg(next_task, nx_off, nx_end);        // consumed after this task's phase 1 (prefetch decision) and by the next iteration
         asm volatile("" ::: "memory");              // (keeps these loads in front of the ring requests below: the counted waits rely on it)
         uint32_t fill = 0;   // wave-uniform: entries used in the LDS list
@@ -1180,7 +1289,12 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         };
         auto ring_refill = [&]() {                              // request what the ring has room for, in chunk order
             if (ring_head < ring_tail) { ring_head = ring_tail; if (ring_landed < ring_tail) ring_landed = ring_tail; }
-            while (ring_head < ring_end && ring_head - ring_tail < RING_CHUNKS) { ring_dma(rs_ring, ring_c0, sk_total ? ring_phys(ring_head) : ring_head, ring_head); ++ring_head; }
+            if (BLU_MIXED_RING && sk_total) {
+                while (ring_head < ring_end && ring_head - ring_tail < RING_CHUNKS) { ring_dma(rs_ring, ring_c0, ring_phys(ring_head), ring_head); ++ring_head; }
+            } else {
+                const uint32_t lim = ring_end < ring_tail + RING_CHUNKS ? ring_end : ring_tail + RING_CHUNKS;
+                if (ring_head < lim) { ring_dma_run(rs_ring, ring_c0, ring_head, lim); ring_head = lim; }
+            }
         };
         // FULL (every streamed segment of the round has at least RPL rows): the lane that would run past the end of its segment
         // takes the segment's LAST RPL rows instead — rows it shares with the lane before it are cleared from its top-row mask —
@@ -1243,9 +1357,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 if (LPQ >= 8) M = imax(M, dpp<0x141>(M));             // row_half_mirror
                 if (LPQ >= 16) M = imax(M, dpp<0x140>(M));            // row_mirror
                 if (BLU_X_SCAN_MIN) { if (sub == 0) L.meta[qi] = (uint32_t)M & 0xFFu; continue; }
-                uint32_t mask = 0;                                    // bit RPL - 1 - i = row i ties on the query's top score
-#pragma unroll
-                for (uint32_t i = 0; i < RPL; ++i) mask = (mask << 1) | (uint32_t)(b[i] == M);
+                uint32_t mask = tie_mask<RPL>(b, M);                  // bit RPL - 1 - i = row i ties on the query's top score
                 mask = left > 0 ? mask : 0u;
                 if constexpr (FULL) mask &= 0xFFFFFFFFu >> (32u - RPL + over);   // rows 0 .. over - 1 are the previous lane's
                 const uint32_t c = (uint32_t)__builtin_popcount(mask);
@@ -1684,8 +1796,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             asm volatile("" : "+v"(n_off), "+v"(n_end));
             if (n_end > n_hits32) n_end = n_hits32;
             if (n_off > n_end) n_off = n_end;
-            const uint64_t nq0 = next_task * WAVE;
-            const uint32_t nqn = (uint32_t)((h.n_queries - nq0) < WAVE ? (h.n_queries - nq0) : WAVE);
+            const uint32_t nqn = task_nq(next_task);
             const uint32_t n_start = (uint32_t)rl((int)n_off, 0);
             const bool n_span = n_off >= n_start && (n_end - n_start) <= (uint32_t)TASK_SPAN;
             const uint32_t rel_end = n_end - n_start, rel_off = n_off - n_start;
@@ -1702,7 +1813,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         auto prefetch_next = [&]() {
             if (nxt_lim > nxt_c0) {
                 const auto rsn = ring_desc(nxt_c0);
-                for (uint32_t c = nxt_c0; c < nxt_lim; ++c) ring_dma(rsn, nxt_c0, c, c);
+                ring_dma_run(rsn, nxt_c0, nxt_c0, nxt_lim);
                 ring_head = nxt_lim; ring_landed = nxt_c0; ring_tail = nxt_c0;
                 pref_task = next_task;
             }
@@ -1714,6 +1825,14 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
+#if defined(BLU_EXPERIMENTS) && defined(BLU_X_PAD_VALU)
+        {   // (timing only: BLU_X_PAD_VALU independent vector instructions per round — is the kernel bound by instruction issue?)
+            uint32_t pad0 = (uint32_t)lane, pad1 = fill;
+#pragma unroll
+            for (int i = 0; i < BLU_X_PAD_VALU / 2; ++i) { asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad0)); asm volatile("v_xor_b32 %0, %0, %0" : "+v"(pad1)); }
+            asm volatile("" ::"v"(pad0), "v"(pad1));
+        }
+#endif
         // ---------------- phase 2a: lane = query, LDS only ----------------
         // One pass over the list entries of every query at once: the trip count is the task's largest top group, a lane
         // whose group is shorter re-reads its last entry (every update below is idempotent), so there is no divergent
@@ -1821,11 +1940,11 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             if (pend) {
                 bool done = true;
                 if (nrows == 0) { pack_status(ra, rb, BLU_ST_NO_HITS, 0xFFFFFFFFu); rec_kind = 1; }   // mod.rs:107-113
-                else if (nrows > MAX_TASK_SEG || !in_span) { if (!BLU_X_SKIP_PUSH) wl_q[atomicAdd(wl_cnt, 1u)] = (uint32_t)q; }
+                else if (nrows > MAX_TASK_SEG || !in_span) { if (!BLU_X_SKIP_PUSH) wl_push(wl_q, wl_cnt, (uint32_t)q); }
                 else if (m & META_SLOW) done = false;   // its step did not fit the list this round: again in the next one
                 else if (dn_flag == 1) mode = dn_k == 1 ? 2u : 0u;                                    // reduced by a dense step
                 else if (dn_flag == 2) { pack_status(ra, rb, dn_err, row0 + dn_pos); rec_kind = 1; }
-                else if (dn_flag == 3) wl_q[atomicAdd(wl_cnt, 1u)] = (uint32_t)q;
+                else if (dn_flag == 3) wl_push(wl_q, wl_cnt, (uint32_t)q);
                 else if (BLU_X_SKIP_2A) { mode = 2; r_row = L.rec[m & 0xFF].x & ROW_MASK; r_len = 5; minlen = 5; }
                 else if (err) { pack_status(ra, rb, err, row0 + err_pos); rec_kind = 1; }
                 else if (!PID32 && nan_pos != 0xFFFFFFFFu) { pack_status(ra, rb, BLU_ST_ERR_BAD_PIDENT, row0 + nan_pos); rec_kind = 1; }
@@ -1845,7 +1964,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        if (pend) wl_q[atomicAdd(wl_cnt, 1u)] = (uint32_t)q;   // a single step larger than the whole list
+        if (pend) wl_push(wl_q, wl_cnt, (uint32_t)q);   // a single step larger than the whole list
 
         // ---------------- phase 2c: lane = query, cutoff tests and the record ----------------
         if (BLU_X_SKIP_2C) { if (mode != 3) { pack_status(ra, rb, mode, r_row + minlen + r_pos + r_len + g_lo + g_hi); rec_kind = 1; } }
@@ -2158,13 +2277,11 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     // last one running, works it off itself (every other block has finished and published its entries).
     __shared__ uint32_t s_drain, s_last;
     uint32_t* const s_cnt = s_lds[0].meta;   // (the queues' lengths, for the drain below: the first wave's task table is dead by now)
-    if (no_long) {
-        // The entries this wave queued are read by the last block of THIS kernel (no kernel boundary in between): every wave makes
-        // its own stores visible at agent scope before the block's ticket — the barrier below is a workgroup-scope release and
-        // does not wait for other waves' stores to have left the CU.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    }
+    // The entries this wave queued (write-through stores, wl_push) may be read by the last block of THIS kernel: every wave
+    // waits for its own stores before the block's ticket — the barrier below is a workgroup-scope release and does not wait
+    // for other waves' stores to have left the CU.  (An agent-scope release fence here — an L2 write-back per wave — cost
+    // 0.08 ms per C3 run and 0.11 ms per C4 slice: measured and replaced by the sc1 stores.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -2585,7 +2702,7 @@ static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hip
     const uint32_t forced = ((known_kind == 1u || known_kind == 2u) ? 1u : 0u) | (no_long ? 2u : 0u);
     if (known_kind != 2u) {
         constexpr uint32_t block_r = (LAYOUT == 0 || LAYOUT == 3) ? BLOCK_F : BLOCK_A;
-        const uint64_t want = (n_tasks + (block_r / WAVE) - 1) / (block_r / WAVE);
+        const uint64_t want = BLU_TAIL_SPLIT ? (hits.n_queries + 16ull * (block_r / WAVE) - 1) / (16ull * (block_r / WAVE)) : (n_tasks + (block_r / WAVE) - 1) / (block_r / WAVE);
         const uint32_t grid = (uint32_t)(want < cus ? (want ? want : 1) : cus);
         g_grid = grid;
         g_block = block_r;
@@ -2593,7 +2710,7 @@ static int launch_t(const TaxDev& tax, const HitsDev& hits, blu_result* out, hip
     }
     if (known_kind != 1u) {
         constexpr uint32_t block_n = (LAYOUT == 0 || LAYOUT == 3) ? BLOCK_A : BLOCK_N;
-        const uint64_t want = (n_tasks + (block_n / WAVE) - 1) / (block_n / WAVE);
+        const uint64_t want = BLU_TAIL_SPLIT ? (hits.n_queries + 16ull * (block_n / WAVE) - 1) / (16ull * (block_n / WAVE)) : (n_tasks + (block_n / WAVE) - 1) / (block_n / WAVE);
         const uint32_t grid = (uint32_t)(want < cus ? (want ? want : 1) : cus);
         if (known_kind == 2u) { g_grid = grid; g_block = block_n; }
         hipLaunchKernelGGL((blu_consensus_stream_kernel<STRAT, LAYOUT, false>), dim3(grid), dim3(block_n), 0, s, hits, tax, out, worklist, work_count, forced, host_len);

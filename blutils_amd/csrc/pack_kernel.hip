@@ -44,16 +44,44 @@ __host__ __device__ inline bool make16(uint32_t row, const double* pid, const ui
     return ok;
 }
 
+// Four rows per thread, a block stride apart: the sixteen column loads of a thread are in flight together (the one-row-per-thread
+// form had 16 bytes in flight per lane and ran at 5 TB/s of its 32 B/row; this is a copy, it should run at the copy rate) and every
+// load / store instruction of a wave still covers contiguous memory (4-byte columns: 256 B, records: 1 KiB).  Columns and records
+// are touched once: non-temporal both ways.
+#define PACK_ROWS 4
 __global__ __launch_bounds__(256) void pack16_kernel(const uint32_t* __restrict__ tax_row, const double* __restrict__ pid,
                                                       const uint32_t* __restrict__ pm, const int32_t* __restrict__ aln,
                                                       const uint32_t* __restrict__ acc, uint64_t n, const uint16_t* __restrict__ hint_of_pos,
                                                       uint64_t n_tax, uint4* __restrict__ out, uint32_t* __restrict__ bad) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t row = tax_row[i];
-    uint32_t w1;
-    if (!make16(row, pid, pm, i, hint_of_pos, n_tax, &w1)) *bad = 1u;
-    out[i] = make_uint4(row, w1, (uint32_t)aln[i], acc[i]);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t tile = (uint64_t)blockDim.x * PACK_ROWS;
+    bool any_bad = false;
+    for (uint64_t base = (uint64_t)blockIdx.x * tile; base < n; base += (uint64_t)gridDim.x * tile) {
+        uint32_t row[PACK_ROWS], k[PACK_ROWS], al[PACK_ROWS], ac[PACK_ROWS];
+        double pd[PACK_ROWS];
+#pragma unroll
+        for (int r = 0; r < PACK_ROWS; ++r) {
+            const uint64_t i = base + (uint64_t)r * blockDim.x + threadIdx.x;
+            const bool on = i < n;
+            const uint64_t j = on ? i : 0;
+            row[r] = __builtin_nontemporal_load(tax_row + j);
+            if (pm) k[r] = __builtin_nontemporal_load(pm + j); else pd[r] = __builtin_nontemporal_load(pid + j);
+            al[r] = (uint32_t)__builtin_nontemporal_load(aln + j);
+            ac[r] = __builtin_nontemporal_load(acc + j);
+        }
+#pragma unroll
+        for (int r = 0; r < PACK_ROWS; ++r) {
+            const uint64_t i = base + (uint64_t)r * blockDim.x + threadIdx.x;
+            if (i >= n) continue;
+            bool ok = true;
+            if (!pm) ok = exact_milli(pd[r], &k[r]);
+            ok = ok && k[r] < BLU_PACKED_PIDENT_LIMIT;
+            any_bad |= !ok;
+            const u32x4 rec = {row[r], (k[r] & BLU_KTHR_NEVER) | (hint_of(row[r], hint_of_pos, n_tax) << BLU_KTHR_BITS), al[r], ac[r]};
+            __builtin_nontemporal_store(rec, reinterpret_cast<u32x4*>(out) + i);
+        }
+    }
+    if (any_bad) *bad = 1u;
 }
 
 __global__ __launch_bounds__(256) void pack24_kernel(const uint32_t* __restrict__ tax_row, const double* __restrict__ pid,
@@ -110,7 +138,8 @@ int blu_hits_pack(const blu_taxonomy* tax, const blu_hits* c, uint32_t* out, voi
     uint32_t bad = 0;
     hipError_t e = hipMemsetAsync(d_bad, 0, 4, s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->tax_row, c->pident, c->pident_milli, c->align_len,
+        const uint64_t tiles = (n + 256 * PACK_ROWS - 1) / (256 * PACK_ROWS), cap = (uint64_t)(tax->num_cus > 0 ? tax->num_cus : 256) * 16;
+        hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(256), 0, s, c->tax_row, c->pident, c->pident_milli, c->align_len,
                            c->acc_rank, n, tax->d_hint_of_pos, tax->n_tax, reinterpret_cast<uint4*>(out), d_bad);
         e = hipGetLastError();
     }
