@@ -75,6 +75,7 @@ int blu_consensus_run(const blu_taxonomy* tax, const blu_hits* hits, const blu_r
     if (params->strategy != BLU_CAUTIOUS && params->strategy != BLU_RELAXED) { set_error("unknown strategy %d", params->strategy); return BLU_ERR_INVALID_ARG; }
     if (hits->n_hits >= 0xFFFFFFFFull) { set_error("n_hits must be < 2^32 - 1 per call"); return BLU_ERR_INVALID_ARG; }
     if (hits->n_queries == 0) return BLU_OK;
+    if (hits->n_queries >= 0xFFFFFFFFull) { set_error("n_queries must be < 2^32 - 1 per call"); return BLU_ERR_INVALID_ARG; }   // (worklist entries and task arithmetic are 32-bit)
     if (!out || !hits->seg_off) { set_error("null output or seg_off"); return BLU_ERR_INVALID_ARG; }
     if (hits->n_hits && (!hits->bitscore || (!hits->packed && !hits->packed64 && (!hits->tax_row || !hits->align_len || !hits->acc_rank)))) {
         set_error("null hit column"); return BLU_ERR_INVALID_ARG;

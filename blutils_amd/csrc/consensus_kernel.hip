@@ -389,12 +389,12 @@ __device__ __forceinline__ uint32_t wide_node(const uint2 e, const uint32_t lo) 
     const uint32_t w = o >= s2 ? (e.y & 0xFFFFu) : (o >= s1 ? e.x >> 16 : e.x & 0xFFFFu);
     return s1 == BLU_WBLK_OVERFLOW ? 0xFFFFFFFFu : w;
 }
-__device__ __forceinline__ uint32_t chain_count(const uint4 c0, const uint4 c1, const uint4 c2, const uint4 c3, const uint32_t hi) {
-    return (uint32_t)(c0.x > hi) + (uint32_t)(c0.y > hi) + (uint32_t)(c0.z > hi) + (uint32_t)(c0.w > hi) +
-           (uint32_t)(c1.x > hi) + (uint32_t)(c1.y > hi) + (uint32_t)(c1.z > hi) + (uint32_t)(c1.w > hi) +
-           (uint32_t)(c2.x > hi) + (uint32_t)(c2.y > hi) + (uint32_t)(c2.z > hi) + (uint32_t)(c2.w > hi) +
-           (uint32_t)(c3.x > hi) + (uint32_t)(c3.y > hi) + (uint32_t)(c3.z > hi) + (uint32_t)(c3.w > hi);
+__device__ __forceinline__ uint32_t chain_count4(const uint4 c, const uint32_t hi) {
+    return (uint32_t)(c.x > hi) + (uint32_t)(c.y > hi) + (uint32_t)(c.z > hi) + (uint32_t)(c.w > hi);
 }
+// entries of a chain requested together with the reference row (levels 0 .. 11: three 16-byte loads, twelve registers in
+// flight — the fourth group and wchain_hi are asked for only by a wave in which some chain is that deep and still holds hi)
+#define BLU_WCHAIN_FIRST 12u
 
 // Which of a lane's N rows tie on the query's top score, row 0 in the top bit of the N-bit mask: mask = 2 mask + (b == M),
 // four rows per group — four compares into scalar pairs, then four add-with-carry (the compare's lane mask is the carry in).
@@ -622,7 +622,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         for (uint32_t i = threadIdx.x; i < t.n_cutvals; i += BLOCK_T) s_cut[i] = t.cutvals[i];
         __syncthreads();
     }
-    const int lane = lane_id();
+    int lane = lane_id();   // (not const: see BLU_LANE_LAUNDER at the head of the task loop)
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     WaveLds<!PID32, RING>& L = s_lds[wib];
     const uint32_t wl_cap = wl_capacity(h.n_queries);
@@ -640,20 +640,22 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
 #ifndef BLU_TAIL_SPLIT
 #define BLU_TAIL_SPLIT 1
 #endif
-    const uint32_t n_tasks64 = n_q32 / WAVE + ((n_q32 % WAVE) != 0u ? 1u : 0u);
-    const uint32_t t_full = BLU_TAIL_SPLIT ? n_tasks64 / n_waves * n_waves : n_tasks64;   // tasks of the whole rounds
-    const uint32_t q_full = t_full == n_tasks64 ? n_q32 : t_full * WAVE;
-    uint32_t tail_q = WAVE;
-    if (BLU_TAIL_SPLIT) {
-        tail_q = (((n_q32 - q_full) + n_waves - 1u) / n_waves + 7u) / 8u * 8u;   // (at most 64: the tail is less than a round)
-        tail_q = tail_q < 16u ? 16u : (tail_q > WAVE ? WAVE : tail_q);
+    // (kept to three kernel-lifetime scalars — the whole rounds' task count and this wave's own piece: every further one costs
+    // a register the ring build does not have)
+    uint32_t t_full, tail_q0, tail_nq;
+    {
+        const uint32_t n_tasks64 = n_q32 / WAVE + ((n_q32 % WAVE) != 0u ? 1u : 0u);
+        t_full = n_tasks64 / n_waves * n_waves;                         // tasks of the whole rounds
+        const uint32_t q_full = t_full == n_tasks64 ? n_q32 : t_full * WAVE;
+        uint32_t tail_q = WAVE;                                         // (BLU_TAIL_SPLIT = 0: the tail as 64-query tasks, as before)
+        if (BLU_TAIL_SPLIT) {
+            tail_q = (((n_q32 - q_full) + n_waves - 1u) / n_waves + 7u) / 8u * 8u;   // (at most 64: the tail is less than a round)
+            tail_q = tail_q < 16u ? 16u : (tail_q > WAVE ? WAVE : tail_q);
+        }
+        const uint64_t p0 = (uint64_t)q_full + (uint64_t)wave * tail_q;   // this wave's piece of the tail
+        tail_q0 = p0 < n_q32 ? (uint32_t)p0 : n_q32;
+        tail_nq = n_q32 - tail_q0 < tail_q ? n_q32 - tail_q0 : tail_q;
     }
-    const uint32_t n_tasks = t_full + ((n_q32 - q_full) + tail_q - 1u) / tail_q;
-    auto task_q0 = [&](const uint32_t tk) { return tk < t_full ? tk * WAVE : q_full + (tk - t_full) * tail_q; };
-    auto task_nq = [&](const uint32_t tk) {
-        const uint32_t left = n_q32 - task_q0(tk), cap = tk < t_full ? (uint32_t)WAVE : tail_q;
-        return left < cap ? left : cap;
-    };
 
     // ---- the bit-score ring of this wave (see WaveLds).  The table's rows are numbered v = row + mis, where mis (0..3)
     // makes v = 0 fall on a 16-byte boundary of the column; chunk c = rows 256 c .. 256 c + 255 lands in ring slot
@@ -663,7 +665,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     const uint64_t v_total = h.n_hits + mis;
     uint32_t ring_head = 0, ring_landed = 0, ring_tail = 0;   // chunk ids: next to request / all before it have landed / first still needed
     uint32_t ring_c0 = 0, ring_end = 0;                        // chunk the DMA descriptor is based at / end of the task's chunks
-    uint32_t pref_task = 0xFFFFFFFFu;                          // task whose first chunks were requested ahead
+    uint32_t pref_q0 = 0xFFFFFFFFu;                            // first query of the task whose first chunks were requested ahead
     // The DMA is issued as inline assembly (m0 = LDS address of the slot; buffer_load_dwordx4 ... lds) rather than through
     // __builtin_amdgcn_raw_ptr_buffer_load_lds: with the builtin hipcc puts an s_waitcnt vmcnt(0) in front of every LDS
     // read that follows (any LDS access may alias a pending LDS-DMA in its book-keeping), which drains the requests this
@@ -720,23 +722,33 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
     // all row arithmetic in 32 bits.  A corrupt table with high words set reads as some other in-range table: clamped like
     // any other, nothing faults.)
     const uint32_t n_hits32 = (uint32_t)h.n_hits;
-    auto load_seg = [&](const uint32_t tk, uint32_t& o, uint32_t& e) {
+    auto load_seg = [&](const uint32_t tq0, const uint32_t tnq, uint32_t& o, uint32_t& e) {   // (tnq = 0: no such task)
         o = 0; e = 0;
-        if (tk < n_tasks) {
-            const uint64_t q = (uint64_t)task_q0(tk) + (uint32_t)lane;
-            if ((uint32_t)lane < task_nq(tk)) {   // (lanes past the task's queries hold an empty segment)
-                const uint32_t* lo32 = reinterpret_cast<const uint32_t*>(h.seg_off + q);
-                o = lo32[0]; e = lo32[2];
-            }
+        if ((uint32_t)lane < tnq) {   // (lanes past the task's queries hold an empty segment)
+            const uint32_t* lo32 = reinterpret_cast<const uint32_t*>(h.seg_off + ((uint64_t)tq0 + (uint32_t)lane));
+            o = lo32[0]; e = lo32[2];
         }
     };
     uint32_t nx_off, nx_end;
-    load_seg(wave, nx_off, nx_end);
+    // the wave's tasks: wave, wave + n_waves, .. below t_full (64 queries each), then its piece of the tail
+    uint32_t task = wave;
+    bool in_tail = task >= t_full, tail_done = false;
+    load_seg(in_tail ? tail_q0 : task * WAVE, in_tail ? tail_nq : (uint32_t)WAVE, nx_off, nx_end);
     STAMP_DECL
 
-    for (uint32_t task = wave; task < n_tasks; task += n_waves) {
-        const uint64_t q0 = task_q0(task);
-        const uint32_t nq = task_nq(task);
+    for (; !in_tail || (tail_nq != 0u && !tail_done); tail_done = in_tail, task += n_waves, in_tail = task >= t_full) {
+#ifndef BLU_LANE_LAUNDER
+#define BLU_LANE_LAUNDER 1
+#endif
+#if BLU_LANE_LAUNDER
+        // The lane id goes through an opaque statement once per task, so that nothing derived from it is loop-invariant to the
+        // compiler: it had hoisted fifty-odd lane-derived addresses and masks (one instruction each to recompute) out of this loop
+        // into registers of their own for the whole kernel — a third of the register file of a kernel that spills for lack of them.
+        asm volatile("" : "+v"(lane));
+#endif
+        const uint32_t q0_32 = in_tail ? tail_q0 : task * WAVE;
+        const uint64_t q0 = q0_32;
+        const uint32_t nq = in_tail ? tail_nq : (uint32_t)WAVE;
         // the worklist queue this task appends to: by the 64-query block its first query lies in, so that a queue receives what
         // wl_capacity() sized it for whether the tail was cut into pieces or not
         const uint32_t wl_sel = (uint32_t)(q0 / WAVE) & (WL_QUEUES - 1u);
@@ -746,8 +758,11 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         uint32_t my_off = nx_off, my_end = nx_end;
         if (my_end > n_hits32) my_end = n_hits32;   // defend the column reads against a corrupt offset table
         if (my_off > my_end) my_off = my_end;
-        const uint32_t next_task = task + n_waves;
-        load_seg(next_task, nx_off, nx_end);        // consumed after this task's phase 1 (prefetch decision) and by the next iteration
+        // the task after this one: the next whole-round task, else this wave's tail piece, else none (nx_nq = 0)
+        const bool nx_tail = task + n_waves >= t_full;
+        const uint32_t nx_q0 = nx_tail ? tail_q0 : (task + n_waves) * WAVE;
+        const uint32_t nx_nq = in_tail ? 0u : (nx_tail ? tail_nq : (uint32_t)WAVE);
+        load_seg(nx_q0, nx_nq, nx_off, nx_end);     // consumed after this task's phase 1 (prefetch decision) and by the next iteration
         asm volatile("" ::: "memory");              // (keeps these loads in front of the ring requests below: the counted waits rely on it)
         uint32_t fill = 0;   // wave-uniform: entries used in the LDS list
         bool keyed = false;  // wave-uniform: the list of this round holds comparison-ready entries (see gather_list)
@@ -755,7 +770,10 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         uint32_t scan_rpl = 16;   // wave-uniform: rows per lane of this round's ring steps (16 or 32: the descriptor format)
         uint32_t fill_ring = 0;   // wave-uniform: list entries of this round that came from ring steps (lane descriptors until the gather)
         // per-lane (= per-query) results of phase 2a
-        // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb)
+        // mode: 0 multi, 2 single, 3 nothing more to compute; rec_kind: 0 no record (worklist), 1 record in (ra, rb), 2 a status
+        // record — (st_code, st_ref), put together when the records are staged: two registers through the task instead of
+        // eight, and no packed status constant for the compiler to hoist into a register of its own for the whole kernel
+        // (it did, five of them, and spilled one)
         const uint64_t q = q0 + (uint32_t)lane;
         const uint32_t row0 = my_off;
         // (r_len: lineage length of the reference row in bits 0..7, the shape hint of its side record above — packed layout,
@@ -764,6 +782,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         typedef typename PidKey<PID32>::type PK;
         PK r_pid = 0, max_pid = 0;   // fold(0.0, max): find_multi_taxa_consensus.rs:182-185
         uint4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+        uint32_t st_code = 0, st_ref = 0;
         // a query reduced by a dense step (below): 0 no, 1 result in the variables above, 2 parse error in (dn_err, dn_pos),
         // 3 hand to the worklist kernel (a perc_identity that does not fit the packed key)
         uint32_t dn_flag = 0, dn_err = 0, dn_pos = 0, dn_k = 0;
@@ -1680,7 +1699,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             ring_c0 = (uint32_t)(vbase >> 8);
             rs_ring = ring_desc(ring_c0);
             ring_end = task_nrows ? (uint32_t)((vbase + task_nrows - 1u) >> 8) + 1u - sk_total : ring_c0;
-            if (pref_task != task) ring_head = ring_landed = ring_c0;
+            if (pref_q0 != q0_32) ring_head = ring_landed = ring_c0;
             ring_tail = ring_c0;
         }
         STAMP(0)   // task set-up: offsets, descriptors, contiguity
@@ -1789,14 +1808,14 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         // requested now and travel while this task finishes (its offsets were requested when this task began).
         const bool last_round = __ballot(pend && (my_end - my_off) != 0u && (my_end - my_off) <= MAX_TASK_SEG && in_span && (L.meta[lane] & META_SLOW)) == 0ull;
         uint32_t nxt_c0 = 0, nxt_lim = 0;
-        if (RING && last_round && next_task < n_tasks) {
+        if (RING && last_round && nx_nq != 0u) {
             // (opaque to the optimizer: otherwise what follows is hoisted out of the rounds loop to right behind the load and
             // the task would start by waiting for the next task's offsets)
             uint32_t n_off = nx_off, n_end = nx_end;
             asm volatile("" : "+v"(n_off), "+v"(n_end));
             if (n_end > n_hits32) n_end = n_hits32;
             if (n_off > n_end) n_off = n_end;
-            const uint32_t nqn = task_nq(next_task);
+            const uint32_t nqn = nx_nq;
             const uint32_t n_start = (uint32_t)rl((int)n_off, 0);
             const bool n_span = n_off >= n_start && (n_end - n_start) <= (uint32_t)TASK_SPAN;
             const uint32_t rel_end = n_end - n_start, rel_off = n_off - n_start;
@@ -1815,7 +1834,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 const auto rsn = ring_desc(nxt_c0);
                 ring_dma_run(rsn, nxt_c0, nxt_c0, nxt_lim);
                 ring_head = nxt_lim; ring_landed = nxt_c0; ring_tail = nxt_c0;
-                pref_task = next_task;
+                pref_q0 = nx_q0;
             }
         };
         if (list_round && !BLU_X_SKIP_GATHER) gather_list(prefetch_next);
@@ -1939,15 +1958,15 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             }
             if (pend) {
                 bool done = true;
-                if (nrows == 0) { pack_status(ra, rb, BLU_ST_NO_HITS, 0xFFFFFFFFu); rec_kind = 1; }   // mod.rs:107-113
+                if (nrows == 0) { st_code = BLU_ST_NO_HITS; st_ref = 0xFFFFFFFFu; rec_kind = 2; }   // mod.rs:107-113
                 else if (nrows > MAX_TASK_SEG || !in_span) { if (!BLU_X_SKIP_PUSH) wl_push(wl_q, wl_cnt, (uint32_t)q); }
                 else if (m & META_SLOW) done = false;   // its step did not fit the list this round: again in the next one
                 else if (dn_flag == 1) mode = dn_k == 1 ? 2u : 0u;                                    // reduced by a dense step
-                else if (dn_flag == 2) { pack_status(ra, rb, dn_err, row0 + dn_pos); rec_kind = 1; }
+                else if (dn_flag == 2) { st_code = dn_err; st_ref = row0 + dn_pos; rec_kind = 2; }
                 else if (dn_flag == 3) wl_push(wl_q, wl_cnt, (uint32_t)q);
                 else if (BLU_X_SKIP_2A) { mode = 2; r_row = L.rec[m & 0xFF].x & ROW_MASK; r_len = 5; minlen = 5; }
-                else if (err) { pack_status(ra, rb, err, row0 + err_pos); rec_kind = 1; }
-                else if (!PID32 && nan_pos != 0xFFFFFFFFu) { pack_status(ra, rb, BLU_ST_ERR_BAD_PIDENT, row0 + nan_pos); rec_kind = 1; }
+                else if (err) { st_code = err; st_ref = row0 + err_pos; rec_kind = 2; }
+                else if (!PID32 && nan_pos != 0xFFFFFFFFu) { st_code = BLU_ST_ERR_BAD_PIDENT; st_ref = row0 + nan_pos; rec_kind = 2; }
                 else {
                     r_len = b_len | (l_hint << 8) | (l_keyed << 30); r_pid = b_pid; r_row = l_row; r_pos = l_pos; minlen = l_minlen; max_pid = l_maxpid;
                     mode = k == 1 ? 2u : 0u;
@@ -1967,7 +1986,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         if (pend) wl_push(wl_q, wl_cnt, (uint32_t)q);   // a single step larger than the whole list
 
         // ---------------- phase 2c: lane = query, cutoff tests and the record ----------------
-        if (BLU_X_SKIP_2C) { if (mode != 3) { pack_status(ra, rb, mode, r_row + minlen + r_pos + r_len + g_lo + g_hi); rec_kind = 1; } }
+        if (BLU_X_SKIP_2C) { if (mode != 3) { st_code = mode; st_ref = r_row + minlen + r_pos + r_len + g_lo + g_hi; rec_kind = 2; } }
         else if (mode != 3) {
             const bool single = mode == 2;
             rec_kind = 1;
@@ -2040,11 +2059,14 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 // the chain of the deepest wide node around lo (row 0 of the table: no such node -> nothing shared)
                 const uint32_t wn = wide_node(wentry, g_lo);
                 const uint4* ch = reinterpret_cast<const uint4*>(t.wchain + (uint64_t)(wn == 0xFFFFFFFFu ? 0u : wn) * BLU_WCHAIN);
-                const uint4 c0 = ch[0], c1 = ch[1], c2 = ch[2], c3 = ch[3];
-                d_tab = chain_count(c0, c1, c2, c3, g_hi);
-                if (t.wide_levels > BLU_WCHAIN && d_tab == BLU_WCHAIN) {     // (deep taxonomies: levels 16 .. 31 of the chain)
-                    const uint4* cg = reinterpret_cast<const uint4*>(t.wchain_hi + (uint64_t)wn * BLU_WCHAIN);
-                    d_tab += chain_count(cg[0], cg[1], cg[2], cg[3], g_hi);
+                const uint4 c0 = ch[0], c1 = ch[1], c2 = ch[2];
+                d_tab = chain_count4(c0, g_hi) + chain_count4(c1, g_hi) + chain_count4(c2, g_hi);
+                if (t.wide_levels > BLU_WCHAIN_FIRST && d_tab == BLU_WCHAIN_FIRST) {   // (a chain deeper than 12 levels that holds hi that far)
+                    d_tab += chain_count4(ch[3], g_hi);
+                    if (t.wide_levels > BLU_WCHAIN && d_tab == BLU_WCHAIN) {           // (deep taxonomies: levels 16 .. 31)
+                        const uint4* cg = reinterpret_cast<const uint4*>(t.wchain_hi + (uint64_t)wn * BLU_WCHAIN);
+                        d_tab += chain_count4(cg[0], g_hi) + chain_count4(cg[1], g_hi) + chain_count4(cg[2], g_hi) + chain_count4(cg[3], g_hi);
+                    }
                 }
                 if (wn == 0xFFFFFFFFu) d_tab = shared_levels(t, g_lo, g_hi);
             } else if (wide) d_tab = shared_levels(t, g_lo, g_hi);
@@ -2070,7 +2092,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             }
             STAMP(5)   // shared levels from the run lengths (or the RMQ tables)
             const bool agree = single | (d >= minlen);
-            if (!agree && d == 0) pack_status(ra, rb, BLU_ST_ERR_ROOT_DISAGREE, row0 + r_pos);   // `index - 1` underflow (:181)
+            if (!agree && d == 0) { st_code = BLU_ST_ERR_ROOT_DISAGREE; st_ref = row0 + r_pos; rec_kind = 2; }   // `index - 1` underflow (:181)
             else {
                 const uint32_t shape = umin(r_hdr >> 8, t.n_shapes - 1u);
                 const uint32_t* codes = t.codes + (uint64_t)shape * t.cstride;
@@ -2205,7 +2227,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 };
                 if (agree) A = F;                                                  // single hit / single-flag branch (:74-75)
                 if (single) {
-                    if (!A) pack_status(ra, rb, BLU_ST_ERR_SINGLE_BELOW_CUTOFFS, row0 + r_pos);   // find_single_query_consensus.rs:113-119
+                    if (!A) { st_code = BLU_ST_ERR_SINGLE_BELOW_CUTOFFS; st_ref = row0 + r_pos; rec_kind = 2; }   // find_single_query_consensus.rs:113-119
                     else {
                         const uint32_t last = (uint32_t)last_lane(A);
                         uint32_t rank_last, mar_unused;
@@ -2239,6 +2261,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         uint4* rec = L.rec;
+        if (rec_kind == 2) pack_status(ra, rb, st_code, st_ref);
         rec[2 * lane] = ra;
         rec[2 * lane + 1] = rb;
         L.meta[lane] = rec_kind;

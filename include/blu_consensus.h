@@ -196,7 +196,9 @@ const char* blu_taxonomy_rank_name(const blu_taxonomy* tax, uint32_t rank_code, 
 int32_t blu_taxonomy_row_cutoffs(const blu_taxonomy* tax, uint64_t desc_row, uint32_t cap, double* cutoff,
                                  uint8_t* is_default, uint16_t* rank_code);
 /* taxid -> ENGINE row id (BLU_UNMATCHED_TAXID when absent); needs desc.taxid at create.  This is the join of
- * the hit table with the taxonomy (mod.rs:72-76); its output is what blu_hits.tax_row holds. */
+ * the hit table with the taxonomy (mod.rs:72-76); its output is what blu_hits.tax_row holds.  A taxid the descriptor
+ * lists more than once maps to its FIRST row (the reference's left join would multiply the hit rows: the whole-use-case
+ * path of blu_pipeline.h does; blutils' own databases have unique taxids). */
 int blu_taxonomy_lookup(const blu_taxonomy* tax, const int64_t* taxid, uint64_t n, uint32_t* out_row);
 /* desc row index -> engine row id for every row of the table (out_map[n_tax]); inverse in out_inverse[n_tax]
  * (either may be NULL).  For callers that already hold desc row indices. */
