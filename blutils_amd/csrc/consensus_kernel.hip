@@ -513,8 +513,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef BLU_REF_NT
 #define BLU_REF_NT 0   // reference-row loads non-temporal (experiment)
 #endif
-#ifndef BLU_WENTRY_EARLY
-#define BLU_WENTRY_EARLY 0   // 1: the wide-node block entry is requested at the end of phase 2a instead of at the head of phase 2c (experiment)
+#ifndef BLU_PRIO_LONG
+#define BLU_PRIO_LONG 0   // 1: the worklist kernel's finalisation (side-record gather, reference row, record) at raised wave priority (experiment)
 #endif
 #ifndef BLU_PRIO
 #define BLU_PRIO 0   // 1: raised wave priority from the gather to the request of the reference rows (experiment, see DESIGN)
@@ -793,9 +793,6 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         // a query reduced by a dense step (below): 0 no, 1 result in the variables above, 2 parse error in (dn_err, dn_pos),
         // 3 hand to the worklist kernel (a perc_identity that does not fit the packed key)
         uint32_t dn_flag = 0, dn_err = 0, dn_pos = 0, dn_k = 0;
-        // the wide-node block entry of g_lo, requested as soon as phase 2a knows the span (BLU_WENTRY_EARLY): by phase 2c it has arrived
-        uint2 wentry_pre = make_uint2(0u, 0u);
-        bool wentry_have = false;
         bool in_span = true;
         // One buffer descriptor per column, based at the task's first row and TASK_SPAN rows long: 32-bit lane byte
         // offsets (< 2^31 also for the 8-byte column), no 64-bit VALU address math, and the hardware range check
@@ -1847,7 +1844,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 pref_q0 = nx_q0;
             }
         };
-        if (BLU_PRIO) __builtin_amdgcn_s_setprio(2);
+        if (BLU_PRIO) __builtin_amdgcn_s_setprio(BLU_PRIO == 2 || BLU_PRIO >= 4 ? 3 : 2);
         if (list_round && !BLU_X_SKIP_GATHER) gather_list(prefetch_next);
         else prefetch_next();
         STAMP(2)   // next-task decision, gather issue + wait + list write
@@ -1982,10 +1979,6 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                     r_len = b_len | (l_hint << 8) | (l_keyed << 30); r_pid = b_pid; r_row = l_row; r_pos = l_pos; minlen = l_minlen; max_pid = l_maxpid;
                     mode = k == 1 ? 2u : 0u;
                     g_lo = lo; g_hi = hi;    // span of the group in sorted order: phase 2c turns it into the shared levels
-                    if (BLU_WENTRY_EARLY && t.wblk != nullptr && !BLU_WIDE_RMQ && k != 1u && hi - lo > BLU_ROW_RUN_MAX) {   // (a superset of the wide groups)
-                        wentry_pre = t.wblk[lo >> BLU_WBLK_SHIFT];
-                        wentry_have = true;
-                    }
                 }
                 if (done) { pend = false; L.seg[lane].y = 0u; }   // later rounds skip it
             }
@@ -2027,8 +2020,9 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
             const bool wide = spread && (dl > BLU_ROW_RUN_MAX || dh > BLU_ROW_RUN_MAX);   // saturated run lengths: not decidable from the row
 #endif
             const bool wide_tab = wide && t.wblk != nullptr && !BLU_WIDE_RMQ;
-            uint2 wentry = wentry_pre;
-            if (wide_tab && !wentry_have) wentry = t.wblk[g_lo >> BLU_WBLK_SHIFT];
+            // (requesting the entry at the end of phase 2a instead, a hundred instructions earlier, changed nothing: 0.9866 vs 0.9863 ms)
+            uint2 wentry = make_uint2(0u, 0u);
+            if (wide_tab) wentry = t.wblk[g_lo >> BLU_WBLK_SHIFT];
             const uint32_t* ref = t.lin + (uint64_t)r_row * t.stride;   // sorted order: row index = pos
             const uint4* ref4 = reinterpret_cast<const uint4*>(ref);
             constexpr bool NODE_RELOAD = ((BLU_NODE_RELOAD_LAYOUTS >> LAYOUT) & 1u) != 0u || (!RING && BLU_NODE_RELOAD_NORING) ||
@@ -2085,7 +2079,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 }
                 if (wn == 0xFFFFFFFFu) d_tab = shared_levels(t, g_lo, g_hi);
             } else if (wide) d_tab = shared_levels(t, g_lo, g_hi);
-            if (BLU_PRIO) __builtin_amdgcn_s_setprio(0);
+            if (BLU_PRIO && BLU_PRIO != 3) __builtin_amdgcn_s_setprio(BLU_PRIO == 4 || BLU_PRIO == 6 ? 1 : (BLU_PRIO == 5 ? 2 : 0));
             STAMP_DRAIN
             STAMP(4)   // reference rows arrive
             r_hdr = w[0].x;   // (requesting it back in phase 2a costs a second fetch: the line leaves L2 in between)
@@ -2399,6 +2393,7 @@ template <int STRAT, int LAYOUT>
 __device__ __forceinline__ void consensus_of_long_query(const HitsDev& h, const TaxDev& t, blu_result* __restrict__ out, const uint64_t q,
                                                         uint32_t* const slot, const int lane) {
     constexpr bool PID32 = LAYOUT == 1 || LAYOUT == 2, PACKED = LAYOUT == 2, WIDE = LAYOUT == 3;
+    if (BLU_PRIO_LONG) __builtin_amdgcn_s_setprio(0);
     uint64_t start = h.seg_off[q], end = h.seg_off[q + 1];
     if (end > h.n_hits) end = h.n_hits;
     if (start > end) start = end;
@@ -2572,6 +2567,7 @@ __device__ __forceinline__ void consensus_of_long_query(const HitsDev& h, const 
     }
     }
     }   // (segments over KEEP_ROWS rows)
+    if (BLU_PRIO_LONG) __builtin_amdgcn_s_setprio(2);   // (the round trips of the finalisation in front of other waves' streaming passes)
     if (kk) flush();
     {
         const uint32_t first_err = wave_min_u32(l_err_row);

@@ -3,7 +3,8 @@ size-independent properties of the path plus an oracle comparison of scattered s
   * shard invariance: two halves run separately == the whole run (ref_row rebased) — queries are independent;
   * query-permutation equivariance: reversing the order of whole queries reverses the records;
   * every record is internally consistent (status / flags / masks);
-  * 40 scattered windows of 2 500 queries are bit-identical to the columnar oracle."""
+  * 40 scattered windows of 2 500 queries are bit-identical to the columnar oracle, and the first four of them — like three of
+    C5's worklist windows — also match the string-faithful oracle field by field (round 4)."""
 import numpy as np
 import pytest
 
@@ -40,6 +41,24 @@ def c3_table():
     import gc
     gc.collect()
     torch.cuda.empty_cache()
+
+
+def _assert_window_matches_faithful(tax, t, sub, window_records):
+    """The engine's records of one window, rendered into the reference's field values, against the STRING-FAITHFUL oracle
+    (oracle/blu_oracle.cpp: per-query row structs, lineage strings parsed per top-group row, the reference's own control
+    flow) fed the same window — not only the columnar restatement of it.  `sub`: the window's columns with desc rows in
+    tax_row and offsets rebased to 0; window_records: the engine's records with ref_row rebased to the window."""
+    from oracle import oracle as orc
+    _, run = orc.faithful_on_synthetic(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, sub["seg_off"], sub["bitscore"],
+                                       sub["tax_row"], sub["pident"], sub["align_len"], sub["acc_rank"], taxon="custom",
+                                       strategy="relaxed", custom=H.CUSTOM_16S, threads=8, want_json=True)
+    faithful = run._json
+    run.close()
+    r = H.Renderer(tax, sub, lambda c: t.rank_name(c), lambda c: t.rank_name(c, serde=True),
+                   lambda row, lvl: bool(t.row_cutoffs(row)[1][lvl]))
+    assert len(faithful) == len(window_records)
+    for q in range(len(window_records)):
+        H.assert_matches_faithful(r.render(window_records[q]), faithful[q], q)
 
 
 def _reverse_queries(hits, n_queries, hits_per_query):
@@ -106,6 +125,7 @@ def test_c3_full_size_properties(c3_table, layout):
     del rev, got, exp
     # --- scattered windows against the oracle
     rng = np.random.default_rng(5)
+    n_win = 0
     for q0 in rng.integers(0, Q - 2500, 40):
         q0 = int(q0)
         r0, r1 = q0 * 50, (q0 + 2500) * 50
@@ -115,6 +135,9 @@ def test_c3_full_size_properties(c3_table, layout):
                "acc_rank": dh.acc_rank[r0:r1].cpu().numpy()}
         o = H.columnar(tax, sub, "custom", "relaxed", H.CUSTOM_16S, threads=8)
         assert shard.rebase_records(o, r0).tobytes() == whole[q0:q0 + 2500].tobytes()
+        n_win += 1
+        if n_win <= 4:           # (the first four windows also against the faithful oracle, field by field)
+            _assert_window_matches_faithful(tax, t, sub, shard.rebase_records(whole[q0:q0 + 2500].copy(), -r0))
 
 
 def test_c5_full_size_properties():
@@ -161,7 +184,7 @@ def test_c5_full_size_properties():
     rng = np.random.default_rng(55)
     long_q = np.nonzero(lens > 512)[0]
     long_q = long_q[long_q < Q - 1500]
-    n_work = 0
+    n_work = n_faith = 0
     for q0 in rng.choice(long_q, 24, replace=False):
         q0 = int(q0)
         q1 = q0 + 1500
@@ -172,6 +195,9 @@ def test_c5_full_size_properties():
                "acc_rank": dh.acc_rank[r0:r1].cpu().numpy()}
         o = H.columnar(tax, sub, "custom", "relaxed", H.CUSTOM_16S, threads=8)
         assert shard.rebase_records(o, r0).tobytes() == whole[q0:q1].tobytes()
+        if n_faith < 3:          # (three windows also against the faithful oracle, field by field)
+            _assert_window_matches_faithful(tax, t, sub, shard.rebase_records(whole[q0:q1].copy(), -r0))
+            n_faith += 1
         n_work += int((lens[q0:q1] > 512).sum())
     assert n_work >= 24 * 100
 
