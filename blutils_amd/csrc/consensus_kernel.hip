@@ -513,11 +513,23 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef BLU_REF_NT
 #define BLU_REF_NT 0   // reference-row loads non-temporal (experiment)
 #endif
+#ifndef BLU_LANE_LAUNDER_LONG
+#define BLU_LANE_LAUNDER_LONG 0   // (the worklist kernel at 64 registers: laundering its lane id moved scratch from 8 to 28 B/lane in the packed build — off)
+#endif
+#ifndef BLU_PRIO_DENSE
+#define BLU_PRIO_DENSE 1   // dense steps of phase 1 (side records fetched and reduced by the scanning lanes) at raised wave priority: zymo-like
+                           // 1.217 -> 1.199 ms, all 50 hits tied 0.548 -> 0.528, C3 0.9554 -> 0.9527 (one box)
+#endif
 #ifndef BLU_PRIO_LONG
-#define BLU_PRIO_LONG 0   // 1: the worklist kernel's finalisation (side-record gather, reference row, record) at raised wave priority (experiment)
+#define BLU_PRIO_LONG 1   // the worklist kernel's finalisation (side-record gather, reference row, record) at raised wave priority: C5 0.4149 -> 0.4110 ms
 #endif
 #ifndef BLU_PRIO
-#define BLU_PRIO 0   // 1: raised wave priority from the gather to the request of the reference rows (experiment, see DESIGN)
+#define BLU_PRIO 4   // wave priority by phase (s_setprio): 0 = none; 4 = level 3 from the request of a task's side records to the request of
+                     // its reference rows — the stretch in which the wave is about to start its next memory round trip, and must not queue
+                     // behind other waves' scan arithmetic, whose data is prefetched anyway — then level 1 for the finalisation, 0 for the
+                     // scan.  One box, medians of seven: C3 0.9074 -> 0.8836 ms, zymo-like 1.179 -> 1.146, 10 hits per query 1.390 -> 1.335,
+                     // f64 side records 1.043 -> 1.021; modes 1 (level 2, back to 0), 2 (level 3), 3 (level 2 to the end of the task) and
+                     // 5 (3 / 2 / 0) within 0.5 % of it
 #endif
 #ifndef BLU_WIDE_RMQ
 #define BLU_WIDE_RMQ 0   // 1: wide groups ask the range-minimum tables as before round 4 (A/B and a test of the fallback)
@@ -1319,7 +1331,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 while (ring_head < ring_end && ring_head - ring_tail < RING_CHUNKS) { ring_dma(rs_ring, ring_c0, ring_phys(ring_head), ring_head); ++ring_head; }
             } else {
                 const uint32_t lim = ring_end < ring_tail + RING_CHUNKS ? ring_end : ring_tail + RING_CHUNKS;
-                if (ring_head < lim) { ring_dma_run(rs_ring, ring_c0, ring_head, lim); ring_head = lim; }
+                if (ring_head < lim) { ring_dma_run(rs_ring, ring_c0, ring_head, lim); ring_head = lim; }   // (raised priority around these requests: no effect)
             }
         };
         // FULL (every streamed segment of the round has at least RPL rows): the lane that would run past the end of its segment
@@ -1406,6 +1418,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
 #define BLU_DENSE_WHEN_FULL 1
 #endif
                 if (PID32 && (BLU_DENSE_WHEN_FULL ? !fits : k0 + k1 + k2 + k3 > CAP)) {
+                    if (BLU_PRIO_DENSE) __builtin_amdgcn_s_setprio(2);   // (its record loads are round trips of the task's own chain)
                     // ---- a DENSE step: the top rows of this step do not fit what is left of the list (many hits tie on the top
                     // score — identical database sequences; round 3: also when the steps before it have filled the list — that used
                     // to end the round and send the rest of the task through phase 1 again: tables with the reference's real
@@ -1556,6 +1569,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                         dn_k = (mine && dn_flag == 1u) ? f_gk : dn_k;   // (a query is reduced in one step only: dn_flag is this step's)
                     }
                     if (sub == 0 && gk != 0u) L.meta[qi] = META_DENSE;
+                    if (BLU_PRIO_DENSE) __builtin_amdgcn_s_setprio(0);
                     continue;
                 }
                 uint32_t idx = rbase + incl - c;                      // list slot of this lane's first top row (file order)
@@ -2665,7 +2679,13 @@ __global__ __launch_bounds__(BLOCK_B, BLU_B_WAVES_PER_SIMD) void blu_consensus_l
     if (wave >= n_work) return;
     const uint32_t cap = wl_capacity(h.n_queries);
     const uint32_t incl = wave_incl_scan_u32(work_count[WL_BASE + (uint32_t)lane * WL_STRIDE + 1u]);   // lane = queue: its published length
-    for (uint32_t wi = wave; wi < n_work; wi += n_waves) consensus_of_long_query<STRAT, LAYOUT>(h, t, out, (uint64_t)wl_entry(worklist, cap, incl, wi), slot, lane);
+    for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
+        int lane_q = lane;
+#if BLU_LANE_LAUNDER_LONG
+        asm volatile("" : "+v"(lane_q));   // (nothing derived from the lane id is loop-invariant: see the stream kernel's task loop)
+#endif
+        consensus_of_long_query<STRAT, LAYOUT>(h, t, out, (uint64_t)wl_entry(worklist, cap, incl, wi), slot, lane_q);
+    }
 }
 
 // ===============================================================================
