@@ -516,12 +516,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef BLU_LANE_LAUNDER_LONG
 #define BLU_LANE_LAUNDER_LONG 0   // (the worklist kernel at 64 registers: laundering its lane id moved scratch from 8 to 28 B/lane in the packed build — off)
 #endif
-#ifndef BLU_SEG_NT
-#define BLU_SEG_NT 0
-#endif
-#ifndef BLU_ROW_LAST_NT
-#define BLU_ROW_LAST_NT 0
-#endif
 #ifndef BLU_PRIO_DENSE
 #define BLU_PRIO_DENSE 1   // dense steps of phase 1 (side records fetched and reduced by the scanning lanes) at raised wave priority: zymo-like
                            // 1.217 -> 1.199 ms, all 50 hits tied 0.548 -> 0.528, C3 0.9554 -> 0.9527 (one box)
@@ -750,8 +744,7 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
         o = 0; e = 0;
         if ((uint32_t)lane < tnq) {   // (lanes past the task's queries hold an empty segment)
             const uint32_t* lo32 = reinterpret_cast<const uint32_t*>(h.seg_off + ((uint64_t)tq0 + (uint32_t)lane));
-            if (BLU_SEG_NT) { o = __builtin_nontemporal_load(lo32); e = __builtin_nontemporal_load(lo32 + 2); }   // (experiment: the offsets are read once)
-            else { o = lo32[0]; e = lo32[2]; }
+            o = lo32[0]; e = lo32[2];
         }
     };
     uint32_t nx_off, nx_end;
@@ -2066,16 +2059,8 @@ void blu_consensus_stream_kernel(HitsDev h, TaxDev t, blu_result* __restrict__ o
                 for (int k = 0; k < 8; ++k) { const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs_lin, r_row * (t.stride * 4u) + 16u * k, 0, BLU_REF_AUX); w[k] = make_uint4(x.x, x.y, x.z, x.w); }
             }
 #else
-            {
-                constexpr int NW = NODE_RELOAD ? 3 : (int)((BLU_ROW_NODE_BASE + NID_REGS + 3u) / 4u);
 #pragma unroll
-                for (int k = 0; k < NW; ++k) {
-                    if (BLU_ROW_LAST_NT && k == NW - 1) {   // (experiment: the last touch of the line non-temporal, so that the row leaves L2 first)
-                        const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ref) + k);
-                        w[k] = make_uint4(x.x, x.y, x.z, x.w);
-                    } else w[k] = ref4[k];
-                }
-            }
+            for (int k = 0; k < (NODE_RELOAD ? 3 : (int)((BLU_ROW_NODE_BASE + NID_REGS + 3u) / 4u)); ++k) w[k] = ref4[k];
 #endif
             // What the finalisation needs per LEVEL depends on the row's shape only (TaxDev::kthr: threshold, rank code and
             // max-allowed-rank bit in one word per level).  In the packed layout the side record of the reference hit carries
