@@ -525,6 +525,15 @@ def main():
                                       f"restatement of the Rust path (oracle/blu_oracle.cpp), {cores} threads over "
                                       f"queries, {dt:.2f} s wall"}
             log(f"[bench] cpu baseline: {cpu_baseline['value']:.4f} Mq/s on {cores} threads ({dt:.2f}s)")
+            # the non-allocating CPU ceiling — the columnar restatement on the same SoA sample, same threads
+            t0 = time.perf_counter()
+            orc.columnar_run(tax.lin_off, tax.lin_node, tax.lin_rank, tax.rank_names, seg, samp["bitscore"], samp["tax_row"], samp["pident"],
+                             samp["align_len"], samp["acc_rank"], taxon=args.taxon, strategy=args.strategy, custom=custom, threads=cores)
+            dtc = time.perf_counter() - t0
+            cpu_baseline["columnar"] = {"value": S / dtc / 1e6, "unit": "Mqueries/s", "cores": cores, "kind": "port",
+                                        "sample": f"the same {S} queries through the columnar restatement (oracle/blu_oracle_columnar.cpp: interned SoA "
+                                                  f"input, no strings, incl. its per-call table set-up), {dtc:.2f} s wall"}
+            log(f"[bench] cpu baseline (columnar): {cpu_baseline['columnar']['value']:.3f} Mq/s on {cores} threads ({dtc:.2f}s)")
 
     pack_info = None
     if rank == 0 and world == 1 and args.pident in ("packed", "packed64") and not args.no_secondary:
