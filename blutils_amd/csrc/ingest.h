@@ -134,6 +134,10 @@ struct TopTable {
 // fd: the table, open for reading (the text is read with pread straight into pinned staging buffers).
 int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool host_columns, HitTable& ht, std::string* why);
 int download_columns(HitTable& ht);
+// Brings the HIP runtime and the device's null stream up (the first call into the runtime costs 0.06-0.26 s, the first
+// queue another 0.04-0.17 s: whoever comes first pays); the use-case starts it on a thread of its own before it reads
+// the taxonomy file, so that part of that time passes beside host work.  Errors are left to the calls that follow.
+void warm_up_device(int device);
 
 // The engine on the columns the GPU ingest left on the device: taxonomy rows -> engine row ids (fwd = blu_taxonomy_row_map's
 // forward table), perc_identity as milli-percent when every value is exactly k/1000 (checked on the device), one

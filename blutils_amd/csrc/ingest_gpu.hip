@@ -6,8 +6,8 @@
 // to the CPU path untouched (BLU_INGEST_FALLBACK).
 //
 // Stages (all on the handle's device; the kernels on the default stream):
-//   0. upload          pread() into pinned staging slots -> HBM, six reader threads with a stream each; the file is
-//                      never mapped into the process
+//   0. upload          pread() into pinned staging slots -> HBM, three reader threads, all copies on the null stream;
+//                      the file is never mapped into the process
 //   1. line index      newline count per 4 KiB tile -> exclusive scan -> line starts
 //   2. parse           one thread per line: tab scan over aligned 16-byte loads, decimal fast path for the four numeric
 //                      columns (mantissa <= 15 digits and |exp10| <= 22: one IEEE operation, so the value is strtod's),
@@ -207,11 +207,11 @@ struct RowOut {
     uint32_t* tax; double* pid; int32_t* aln; int32_t* bs;
 };
 
-__global__ __launch_bounds__(256) void parse_rows(const unsigned char* __restrict__ text, const uint64_t* __restrict__ line_start, uint32_t n_rows,
-                                                  DevTaxidMap taxmap, RowOut o, uint32_t* __restrict__ flags,
-                                                  unsigned long long* __restrict__ n_unmatched) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows) return;
+// One line, read from global memory a byte at a time through one state machine for all thirteen columns: the form that
+// takes any line length.  parse_rows uses it for the blocks whose 256 lines do not fit its LDS stage.
+__device__ __noinline__ void parse_row_general(const unsigned char* __restrict__ text, const uint64_t* __restrict__ line_start, uint32_t i,
+                                               const DevTaxidMap& taxmap, const RowOut& o, uint32_t* __restrict__ flags,
+                                               unsigned long long* __restrict__ n_unmatched) {
     const uint64_t p = line_start[i];
     uint64_t e = line_start[i + 1] - 1;                 // the newline (or one past the end of a last line without one)
     if (e > p && text[e - 1] == '\r') --e;
@@ -261,6 +261,97 @@ __global__ __launch_bounds__(256) void parse_rows(const unsigned char* __restric
         !(v_tax >= -9.2e18 && v_tax <= 9.2e18)) { atomicOr(flags, FB_RANGE); return; }
     const uint32_t row = taxid_lookup(taxmap, (long long)v_tax);   // left join (mod.rs:72-76)
     if (row == BLU_UNMATCHED_TAXID) atomicAdd(n_unmatched, 1ull);
+    o.tax[i] = row; o.pid[i] = v_pid; o.aln[i] = (int32_t)v_aln; o.bs[i] = (int32_t)bs_t;
+}
+
+// The parse kernel proper: a block takes 256 consecutive lines, whose text is one contiguous span of the file (17 KB for
+// BLAST's usual 67-byte lines).  The span is staged in LDS with coalesced 16-byte loads; every lane then (1) finds the
+// tabs of its line with word-wide compares and leaves their positions in LDS, (2) walks the six columns the engine
+// reads ONE COLUMN AT A TIME, so that the 64 lanes of a wave are in the same column and the same branch of the same
+// small loop: the one-state-machine-per-line form above spends its time in divergence (a wave has lanes in every
+// column at once and runs the end-of-field code of all of them at nearly every byte) and in instruction fetch (the
+// 16-byte unrolled body does not fit the instruction cache).  Same grammar, same hashes, same flags as the general form;
+// a block whose span exceeds the stage (lines of 128 bytes and more on average) is parsed by the general form.
+constexpr uint32_t STAGE_BYTES = 32768;
+constexpr int PARSE_THREADS = 256;
+
+__global__ __launch_bounds__(PARSE_THREADS) void parse_rows(const unsigned char* __restrict__ text, const uint64_t* __restrict__ line_start, uint32_t n_rows,
+                                                            DevTaxidMap taxmap, RowOut o, uint32_t* __restrict__ flags,
+                                                            unsigned long long* __restrict__ n_unmatched) {
+    __shared__ uint4 stage16[STAGE_BYTES / 16];
+    __shared__ uint16_t tab_at[13 * PARSE_THREADS];                  // [column][thread]: position of the tab that ends the column
+    const uint32_t r0 = blockIdx.x * PARSE_THREADS, r1 = min(r0 + (uint32_t)PARSE_THREADS, n_rows), i = r0 + threadIdx.x;
+    // (the four line starts travel together: two round trips to memory per block — these, then the text — and no more)
+    const uint64_t ls0 = line_start[r0], s1 = line_start[r1];       // (line_start[n_rows] = one past the last newline, or size + 1)
+    const uint64_t my_p = line_start[min(i, r1 - 1)], my_e = line_start[min(i, r1 - 1) + 1];
+    const uint64_t s0 = ls0 & ~15ull;
+    if (s1 - s0 > STAGE_BYTES) {                                     // uniform over the block
+        if (i < r1) parse_row_general(text, line_start, i, taxmap, o, flags, n_unmatched);
+        return;
+    }
+    {
+        const uint32_t n16 = (uint32_t)((s1 - s0 + 15) >> 4);        // (reads at most 15 bytes past s1 <= size + 1: inside the 64 bytes of padding)
+        const uint4* src = reinterpret_cast<const uint4*>(text + s0);
+        constexpr int PER_THREAD = STAGE_BYTES / 16 / PARSE_THREADS; // all of a thread's loads are in flight before the first is stored
+        uint4 v[PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; ++j) { const uint32_t k = threadIdx.x + (uint32_t)j * PARSE_THREADS; v[j] = src[min(k, n16 - 1)]; }
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; ++j) { const uint32_t k = threadIdx.x + (uint32_t)j * PARSE_THREADS; if (k < n16) stage16[k] = v[j]; }
+    }
+    __syncthreads();
+    if (i >= r1) return;
+    const unsigned char* sb = reinterpret_cast<const unsigned char*>(stage16);
+    const uint32_t* sw = reinterpret_cast<const uint32_t*>(stage16);
+    const uint32_t p = (uint32_t)(my_p - s0);
+    uint32_t e = (uint32_t)(my_e - 1 - s0);                          // the newline (or one past the end of a last line without one)
+    if (e > p && sb[e - 1] == '\r') --e;
+    if (e <= p) { atomicOr(flags, FB_EMPTY_LINE); return; }
+    // ---- (1) the tabs: four bytes per compare (exact zero-byte test on word ^ 0x09090909), bytes outside [p, e) masked off
+    uint32_t n_tabs = 0;
+    for (uint32_t a = p & ~3u; a < e && n_tabs < 13; a += 4) {
+        const uint32_t x = sw[a >> 2] ^ 0x09090909u;
+        uint32_t m = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);   // bit 7 of every byte that is a tab
+        if (a < p) m &= 0xFFFFFFFFu << (8 * (p - a));
+        if (e - a < 4) m &= (1u << (8 * (e - a))) - 1u;
+        while (m && n_tabs < 13) {
+            tab_at[n_tabs * PARSE_THREADS + threadIdx.x] = (uint16_t)(a + ((uint32_t)__builtin_ctz(m) >> 3));
+            ++n_tabs;
+            m &= m - 1;
+        }
+    }
+    if (n_tabs < 12) { atomicOr(flags, FB_COLUMNS); return; }       // fewer than 13 columns
+    auto tab = [&](int c) { return (uint32_t)tab_at[c * PARSE_THREADS + threadIdx.x]; };
+    uint32_t fb = 0;
+    // ---- (2) query and accession: FNV-1a over the field, as in the general form
+    auto hash_field = [&](uint32_t s, uint32_t t) {
+        unsigned long long h = 1469598103934665603ull;
+        for (uint32_t q = s; q < t; ++q) { const uint32_t c = sb[q]; h = hash_step(h, c); if (c == '"') fb |= FB_QUOTE; }
+        return hash_finish(h, t - s);
+    };
+    const uint32_t t0 = tab(0), t1 = tab(1);
+    const unsigned long long qh = hash_field(p, t0), ah = hash_field(t0 + 1, t1);
+    // ---- the four numbers
+    auto number = [&](uint32_t s, uint32_t t, bool integer, double* v) {
+        NumState num;
+        num.reset();
+        for (uint32_t q = s; q < t; ++q) num.feed(sb[q], q == s);
+        if (!num.value(v) || (integer && (num.seen_dot || num.seen_exp))) fb |= FB_NUMBER;
+    };
+    double v_tax = 0, v_pid = 0, v_aln = 0, v_bs = 0;
+    const uint32_t t2 = tab(2), t3 = tab(3);
+    number(t1 + 1, t2, true, &v_tax);                               // (subject_taxid and align_length are Int64 columns, mod.rs:226-244)
+    number(t2 + 1, t3, false, &v_pid);
+    number(t3 + 1, tab(4), true, &v_aln);
+    number(tab(11) + 1, n_tabs == 13 ? tab(12) : e, false, &v_bs);
+    if (fb) { atomicOr(flags, fb); return; }
+    const double bs_t = trunc(v_bs);                                // mod.rs:184 AnyValue::Float64 -> try_extract::<i64> (truncation)
+    if (!(bs_t >= -2147483648.0 && bs_t <= 2147483647.0) || !(v_aln >= -2147483648.0 && v_aln <= 2147483647.0) ||
+        !(v_tax >= -9.2e18 && v_tax <= 9.2e18)) { atomicOr(flags, FB_RANGE); return; }
+    const uint32_t row = taxid_lookup(taxmap, (long long)v_tax);   // left join (mod.rs:72-76)
+    if (row == BLU_UNMATCHED_TAXID) atomicAdd(n_unmatched, 1ull);
+    o.qh[i] = qh; o.qpos[i] = (s0 + p) | ((unsigned long long)(t0 - p) << 44);
+    o.ah[i] = ah; o.apos[i] = (s0 + t0 + 1) | ((unsigned long long)(t1 - t0 - 1) << 44);
     o.tax[i] = row; o.pid[i] = v_pid; o.aln[i] = (int32_t)v_aln; o.bs[i] = (int32_t)bs_t;
 }
 
@@ -470,71 +561,91 @@ struct DeviceArena {
         auto it = std::find(ptrs.begin(), ptrs.end(), p);
         if (it != ptrs.end()) ptrs.erase(it);
     }
-    ~DeviceArena() { for (void* p : ptrs) (void)hipFree(p); }
+    void free_all() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
+    ~DeviceArena() { free_all(); }
 };
 
-// The text goes page cache -> pinned staging -> HBM without ever being mapped into the process: a few reader threads,
-// each with two pinned slots and a stream of its own, pread() a piece while the previous one is on the wire (6.7 GB in
-// 0.22 s including the allocation of the device buffer).  Mapping the file and handing it to one hipMemcpy moves the
-// bytes as fast but leaves 6.7 GB of populated page table behind: unmapping it took 0.08 s and held up every
-// allocation made meanwhile; synchronous copies out of the same pinned slots were 10 % slower.
+// The text goes page cache -> pinned staging -> HBM without ever being mapped into the process: three reader threads,
+// each with two pinned slots, pread() a piece while the previous one is on the wire.  What the parts cost on a box
+// (scripts/probe/upload_probe.hip, 6.7 GB): the copies alone 0.12 s (56 GB/s, the PCIe rate; one stream carries 50 of it),
+// pread alone 30 GB/s per thread, so two or three readers keep the wire busy — and EVERY hipStreamCreate 15 ms (the first
+// one of the process 40-170 ms: an HSA queue each).  Six readers with a stream and a hipHostMalloc each, as this was
+// written first, spent more time setting up than copying.  Hence: one pinned block for all slots, and all copies on the
+// null stream, which the kernels that follow need anyway (in order on one queue: a slot's event still says when it is free).
+// Mapping the file and handing it to hipMemcpy moves the bytes as fast (the runtime pins the page-cache pages) but
+// costs 0.06 s to populate and 0.07-0.10 s to unmap 6.7 GB of page table.
 static int upload_file(int fd, size_t size, unsigned char* d_text, int device, std::string* err) {
-    unsigned nt = 6;
+    unsigned nt = 3;
     if (const char* env = getenv("BLU_UPLOAD_THREADS")) nt = (unsigned)atoi(env);
     const size_t piece = 8u << 20, n_pieces = (size + piece - 1) / piece;
-    nt = std::max(1u, std::min<unsigned>(nt, (unsigned)std::max<size_t>(n_pieces, 1)));
+    nt = std::max(1u, std::min<unsigned>(std::min(nt, 16u), (unsigned)std::max<size_t>(n_pieces, 1)));
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};      // 1: the file could not be read; 2: the staging path could not be set up or used (HIP)
-    std::vector<std::string> errs(nt);
+    std::vector<std::string> errs(nt + 1);
+    auto fail = [&](unsigned t, const char* what, hipError_t e) {
+        errs[t] = std::string(what) + ": " + (e == hipSuccess ? strerror(errno) : hipGetErrorString(e));
+        int none = 0;
+        failed.compare_exchange_strong(none, e == hipSuccess ? 1 : 2);
+    };
+    char* block = nullptr;
+    std::vector<hipEvent_t> events((size_t)nt * 2, nullptr);
+    hipError_t e0 = hipHostMalloc((void**)&block, (size_t)nt * 2 * piece, hipHostMallocDefault);
+    for (size_t k = 0; k < events.size() && e0 == hipSuccess; ++k) e0 = hipEventCreateWithFlags(&events[k], hipEventDisableTiming);
+    if (e0 != hipSuccess) fail(nt, "staging set-up", e0);
     auto work = [&](unsigned t) {
-        char* slots = nullptr;
-        hipStream_t st = nullptr;
-        hipEvent_t ev[2] = {nullptr, nullptr};
+        char* const slots = block + (size_t)t * 2 * piece;
+        hipEvent_t* const ev = &events[(size_t)t * 2];
         bool busy[2] = {false, false};
-        auto fail = [&](const char* what, hipError_t e) {
-            errs[t] = std::string(what) + ": " + (e == hipSuccess ? strerror(errno) : hipGetErrorString(e));
-            int none = 0;
-            failed.compare_exchange_strong(none, e == hipSuccess ? 1 : 2);
-        };
         hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipHostMalloc((void**)&slots, 2 * piece, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-        for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
-        if (e != hipSuccess) fail("staging set-up", e);
+        if (e != hipSuccess) fail(t, "hipSetDevice", e);
         unsigned turn = 0;
         while (!failed.load(std::memory_order_relaxed)) {
             const size_t k = next.fetch_add(1);
             if (k >= n_pieces) break;
             const unsigned sl = turn++ & 1;
-            if (busy[sl] && (e = hipEventSynchronize(ev[sl])) != hipSuccess) { fail("hipEventSynchronize", e); break; }
+            if (busy[sl] && (e = hipEventSynchronize(ev[sl])) != hipSuccess) { fail(t, "hipEventSynchronize", e); break; }
             const size_t off = k * piece, len = std::min(piece, size - off);
             size_t got = 0;
             while (got < len) {
                 const ssize_t r = pread(fd, slots + sl * piece + got, len - got, (off_t)(off + got));
                 if (r < 0 && errno == EINTR) continue;
-                if (r <= 0) { fail("pread", hipSuccess); break; }
+                if (r <= 0) { fail(t, "pread", hipSuccess); break; }
                 got += (size_t)r;
             }
             if (got < len) break;
-            if ((e = hipMemcpyAsync(d_text + off, slots + sl * piece, len, hipMemcpyHostToDevice, st)) != hipSuccess) { fail("hipMemcpyAsync", e); break; }
-            if ((e = hipEventRecord(ev[sl], st)) != hipSuccess) { fail("hipEventRecord", e); break; }
+            if ((e = hipMemcpyAsync(d_text + off, slots + sl * piece, len, hipMemcpyHostToDevice, nullptr)) != hipSuccess) { fail(t, "hipMemcpyAsync", e); break; }
+            if ((e = hipEventRecord(ev[sl], nullptr)) != hipSuccess) { fail(t, "hipEventRecord", e); break; }
             busy[sl] = true;
         }
-        if (st) { e = hipStreamSynchronize(st); if (e != hipSuccess && !failed) fail("hipStreamSynchronize", e); }
-        for (int k = 0; k < 2; ++k) if (ev[k]) (void)hipEventDestroy(ev[k]);
-        if (st) (void)hipStreamDestroy(st);
-        if (slots) (void)hipHostFree(slots);
     };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto& th : pool) th.join();
+    if (!failed) {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
+    }
+    {   // the slots are free once everything queued has been sent (also on the way out of a failure: copies may be in flight)
+        const hipError_t e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess && !failed) fail(nt, "hipStreamSynchronize", e);
+    }
+    for (hipEvent_t ev : events) if (ev) (void)hipEventDestroy(ev);
+    if (block) (void)hipHostFree(block);
     if (failed) {
         for (auto& m : errs) if (!m.empty()) { *err = m; break; }
         (void)hipGetLastError();
         return failed == 1 ? BLU_ERR_IO : BLU_INGEST_FALLBACK;   // (no pinned memory to be had, say: the CPU parser takes the file)
     }
     return BLU_OK;
+}
+
+void warm_up_device(int device) {
+    void* p = nullptr;
+    if (hipSetDevice(device) == hipSuccess && hipMalloc(&p, 64) == hipSuccess) {
+        (void)hipMemsetAsync(p, 0, 64, nullptr);
+        (void)hipStreamSynchronize(nullptr);
+        (void)hipFree(p);
+    }
+    (void)hipGetLastError();
 }
 
 int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool host_columns, HitTable& ht, std::string* why) {
@@ -620,7 +731,7 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     // ---- upload + line index
     lap("device start-up");
     HIPCHK(mem.alloc((void**)&d_text, size + 64));
-    HIPCHK(hipMemset(d_text + size, 0, 64));   // the padding only: the readers' copies run on streams of their own and may not be ordered against this one
+    HIPCHK(hipMemset(d_text + size, 0, 64));   // the padding only (the readers' pieces end at `size`)
     {
         std::string io;
         rc = upload_file(fd, size, d_text, device, &io);
@@ -669,7 +780,7 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     {
         RowOut o{d_qh, d_ah, d_qpos, d_apos, d_tax, d_pid, d_aln, d_bs};
         DevTaxidMap tm{d_taxmap, row_of.tab.size() - 1};
-        hipLaunchKernelGGL(parse_rows, grid(n_rows), dim3(256), 0, 0, d_text, d_line, n_rows, tm, o, d_flags, d_big);
+        hipLaunchKernelGGL(parse_rows, grid(n_rows, PARSE_THREADS), dim3(PARSE_THREADS), 0, 0, d_text, d_line, n_rows, tm, o, d_flags, d_big);
         HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
         if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
     }
@@ -892,6 +1003,9 @@ done:
     if (rc != BLU_OK) {
         ht.clear();
     }
+    lap("hand-over");
+    mem.free_all();
+    lap("free the work buffers");
     return rc;
 }
 

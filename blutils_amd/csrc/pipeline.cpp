@@ -619,6 +619,7 @@ void parallel_for(unsigned n, unsigned nthreads, F&& f) {
 // Afterwards only the DISTINCT strings are merged — queries in file order (first appearance decides a query's
 // position, mod.rs:192-208), accessions by a tree of sorted-list merges (their id is their rank in byte order) —
 // and the workers scatter their rows into the grouped table.  The result does not depend on the thread count.
+thread_local double g_t_body_end = 0;   // stage trace: when build_document's last statement ran (what follows is its tear-down)
 thread_local int g_last_ingest_path = 0;   // 0 = CPU parser, 1 = GPU parser (blu_last_ingest_path)
 
 int load_hits(const char* path, const Db& db, HitTable& ht, int device = -1, bool host_columns = true) {
@@ -1142,6 +1143,10 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
     Trace tr;
     const unsigned nthreads = worker_threads();
     double t0 = now_s();
+    // (HIP start-up beside the reading of the taxonomy file; BLU_INGEST=cpu callers with no device never get here with one)
+    std::thread warm_up;
+    struct JoinWarmUp { std::thread& t; ~JoinWarmUp() { if (t.joinable()) t.join(); } } join_warm_up{warm_up};
+    if (params->device >= 0) warm_up = std::thread([dev = params->device]() { warm_up_device(dev); });
     Db db;
     int rc = load_db(taxonomies_file, params->use_taxid != 0, db);     // mod.rs:64
     if (rc != BLU_OK) return rc;
@@ -1432,6 +1437,7 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
     }
     st.t_render_s = now_s() - t0;
     if (stats) *stats = st;
+    g_t_body_end = now_s();
     return BLU_OK;
 }
 
@@ -1481,6 +1487,7 @@ int blu_build_consensus_identities_to_file(const char* blast_output_file, const 
     try { rc = build_document(blast_output_file, headers, n_headers, taxonomies_file, params, run_id_text, config_text, out_path, &d, stats); }
     catch (const std::bad_alloc&) { set_error("out of memory"); return BLU_ERR_ALLOC; }
     if (rc != BLU_OK) return rc;
+    if (getenv("BLU_INGEST_TRACE")) fprintf(stderr, "[pipeline] %-26s %.3f s\n", "tear-down (tables, strings)", now_s() - g_t_body_end);
     if (d.written) return BLU_OK;
     // (YAML: one piece, written here) write_blutils_output.rs:57-63: an existing file is replaced
     Trace tr;
