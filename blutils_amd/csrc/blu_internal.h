@@ -138,6 +138,7 @@ struct blu_taxonomy {
     std::vector<uint8_t> h_isdef;            // [n_shapes * sc]
     uint32_t n_shapes = 0;
     std::unordered_map<int64_t, uint32_t> taxid_row;
+    unsigned char* d_block = nullptr;   // ONE device allocation; the table pointers below are views into it (a hipFree each cost 1.5-2 ms)
     uint32_t* d_lin = nullptr;
     std::vector<uint32_t> order;             // engine row id -> desc row
     uint8_t* d_lcp8 = nullptr;

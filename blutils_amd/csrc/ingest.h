@@ -92,11 +92,12 @@ struct HitTable {
     std::vector<std::string> accessions;         // sorted (String::cmp)
     uint64_t unmatched = 0;
     uint64_t n_hits = 0;                         // rows of the table (the host columns may be absent, see below)
+    uint64_t n_queries = 0;                      // = query_names.size() once the strings are there (wait_strings())
     bool host_columns = true;                    // false: the GPU ingest was asked to leave the columns on the device only
     std::unique_ptr<DeviceHits> dev;             // set by the GPU ingest
-    // The GPU ingest returns as soon as the device columns are complete; query_names and accessions (already sized) are
-    // still being filled by this thread from the distinct strings the device sent back.  wait_strings() before either
-    // is read.
+    // The GPU ingest returns as soon as the device columns are complete; query_names and accessions are still being
+    // sized and filled by this thread from the distinct strings the device sent back (n_queries is set).  wait_strings()
+    // before either is touched.
     std::thread strings_thread;
     bool strings_ok = true;                      // false: the strings thread ran out of memory (read after wait_strings())
     void wait_strings() { if (strings_thread.joinable()) strings_thread.join(); }
@@ -104,7 +105,7 @@ struct HitTable {
         wait_strings();
         query_names.clear(); accessions.clear();
         seg_off = {}; bitscore = {}; align_len = {}; tax_desc_row = {}; acc_rank = {}; pident = {};
-        unmatched = n_hits = 0; host_columns = true; strings_ok = true;
+        unmatched = n_hits = n_queries = 0; host_columns = true; strings_ok = true;
         dev.reset();
     }
     HitTable() = default;

@@ -17,7 +17,8 @@
 //                      with length + first 12 key bytes; every row then verifies its own text against its slot (a
 //                      mismatch = two strings with one 64-bit hash -> fallback), so ids are exact, not probabilistic
 //   4. ids             queries numbered by first row (radix sort of the distinct entries); accessions ranked in byte
-//                      order on the host (only the distinct strings travel) and the ranks uploaded
+//                      order on the host (only the distinct strings travel; the sort runs on a thread of its own while
+//                      the device builds the query dictionary) and the ranks uploaded
 //   5. grouping        stable radix sort by query id unless the file is grouped already; gathers; segment offsets
 //   6. hand-over       the grouped columns stay on the device for the engine (host copies only on request); the distinct
 //                      query / accession strings come back packed and a background thread turns them into the host
@@ -679,8 +680,8 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     void* d_tmp = nullptr;
     size_t tmp_bytes = 0;
     TaxidMap::E* d_taxmap = nullptr;
-    unsigned long long *d_qh = nullptr, *d_ah = nullptr, *d_qpos = nullptr, *d_apos = nullptr, *d_big = nullptr, *d_poslist = nullptr;
-    uint32_t *d_tax = nullptr, *d_qid = nullptr, *d_arank = nullptr, *d_list_row = nullptr, *d_list_slot = nullptr, *d_list_row2 = nullptr,
+    unsigned long long *d_qh = nullptr, *d_ah = nullptr, *d_qpos = nullptr, *d_apos = nullptr, *d_big = nullptr, *d_poslist = nullptr, *d_aposlist = nullptr;
+    uint32_t *d_tax = nullptr, *d_qid = nullptr, *d_arank = nullptr, *d_list_row = nullptr, *d_list_slot = nullptr, *d_alist_row = nullptr, *d_alist_slot = nullptr, *d_list_row2 = nullptr,
              *d_list_slot2 = nullptr, *d_perm = nullptr, *d_perm2 = nullptr, *d_qid2 = nullptr, *d_ranks = nullptr;
     double *d_pid = nullptr, *d_pid2 = nullptr;
     int32_t *d_aln = nullptr, *d_bs = nullptr, *d_aln2 = nullptr, *d_bs2 = nullptr;
@@ -693,6 +694,11 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     std::vector<char> q_bytes, a_bytes;
     std::vector<unsigned long long> q_off, a_off;
     std::vector<uint32_t> order;
+    std::vector<unsigned long long> k0, k1;      // first 16 bytes of every distinct accession as two big-endian words
+    uint64_t acap = 0;                           // slots of the accession table
+    std::thread acc_sort;                        // the host's sort of the distinct accessions, beside the query dictionary
+    std::atomic<bool> acc_sort_failed{false};
+    struct JoinSort { std::thread& t; ~JoinSort() { if (t.joinable()) t.join(); } } join_acc_sort{acc_sort};
     uint64_t n_tiles = (size + TILE_BYTES - 1) / TILE_BYTES;
     auto need_tmp = [&](size_t bytes) -> hipError_t {
         if (bytes <= tmp_bytes) return hipSuccess;
@@ -786,6 +792,84 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     }
     lap("parse");
 
+    // ---- accession dictionary, first half: distinct count unknown; the table grows until the load stays under one half.
+    // (It comes before the query dictionary so that the host's sort of the distinct accessions — 12 ms for 300 k — runs on a
+    // thread of its own while the device builds the query dictionary.)
+    {
+        uint64_t cap = pow2_at_least(std::min<uint64_t>((uint64_t)n_rows * 2 + 16, 1ull << 20));   // (32 MB: stays in the caches while 100 M rows probe it; x4 when more than half full)
+        for (;;) {
+            HIPCHK(mem.alloc((void**)&d_atab, cap * sizeof(Slot)));
+            lap("  acc: table allocation");
+            hipLaunchKernelGGL(dict_init, grid(cap), dim3(256), 0, 0, d_atab, cap);
+            HIPCHK(hipMemset(d_counter, 0, 4));
+            HIPCHK(hipMemset(d_flags, 0, 4));
+            hipLaunchKernelGGL(dict_insert, grid(n_rows), dim3(256), 0, 0, d_ah, n_rows, d_atab, cap - 1, false, d_counter, d_flags);
+            hipLaunchKernelGGL(dict_count, grid(cap, 1024), dim3(1024), 0, 0, d_atab, cap, d_counter);
+            HIPCHK(hipMemcpy(&n_acc, d_counter, 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
+            if (!(h_flags & FB_TABLE_FULL) && (uint64_t)n_acc * 2 <= cap) break;
+            mem.free(d_atab); d_atab = nullptr;
+            if (cap >= pow2_at_least((uint64_t)n_rows * 2 + 16)) { rc = fallback(fallback_text(FB_TABLE_FULL)); goto done; }
+            cap *= 4;
+        }
+        lap("  acc: insert");
+        HIPCHK(hipMemset(d_flags, 0, 4));
+        HIPCHK(mem.alloc((void**)&d_alist_row, (size_t)n_acc * 4)); HIPCHK(mem.alloc((void**)&d_alist_slot, (size_t)n_acc * 4));
+        HIPCHK(hipMemset(d_counter, 0, 4));
+        hipLaunchKernelGGL(dict_finalize, grid(cap), dim3(256), 0, 0, d_atab, cap, d_text, d_apos, d_alist_row, d_alist_slot, d_counter);
+        HIPCHK(mem.alloc((void**)&d_aposlist, (size_t)n_acc * 8));
+        hipLaunchKernelGGL(gather_pos, grid(n_acc), dim3(256), 0, 0, d_apos, d_alist_row, n_acc, d_aposlist);
+        rc = download_strings(d_aposlist, n_acc, a_bytes, a_off);
+        if (rc != BLU_OK) goto done;
+        lap("  acc: distinct to host");
+        // byte order of the distinct accessions (String::cmp), on the host: only the distinct strings are touched, and
+        // mostly not even those — the GPU hands over their first 16 bytes as two big-endian integers; the text is read
+        // only to order keys that agree on all 16
+        k0.resize(n_acc); k1.resize(n_acc);
+        {
+            unsigned long long *d_k0 = nullptr, *d_k1 = nullptr;
+            HIPCHK(mem.alloc((void**)&d_k0, (size_t)n_acc * 8 + 8));
+            hipError_t e2 = mem.alloc((void**)&d_k1, (size_t)n_acc * 8 + 8);
+            if (e2 == hipSuccess) {
+                hipLaunchKernelGGL(gather_key16, grid(n_acc), dim3(256), 0, 0, d_aposlist, n_acc, d_text, d_k0, d_k1);
+                e2 = hipMemcpy(k0.data(), d_k0, (size_t)n_acc * 8, hipMemcpyDeviceToHost);
+                if (e2 == hipSuccess) e2 = hipMemcpy(k1.data(), d_k1, (size_t)n_acc * 8, hipMemcpyDeviceToHost);
+            }
+            mem.free(d_k0);
+            mem.free(d_k1);
+            HIPCHK(e2);
+        }
+        acap = cap;
+        order.resize(n_acc);
+        for (uint32_t k = 0; k < n_acc; ++k) order[k] = k;
+        acc_sort = std::thread([&]() {
+            try {
+                auto view = [&](uint32_t k) { return std::string_view(a_bytes.data() + a_off[k], (size_t)(a_off[k + 1] - a_off[k])); };
+                auto less = [&](uint32_t a, uint32_t b) {
+                    if (k0[a] != k0[b]) return k0[a] < k0[b];
+                    if (k1[a] != k1[b]) return k1[a] < k1[b];
+                    const size_t la = (size_t)(a_off[a + 1] - a_off[a]), lb = (size_t)(a_off[b + 1] - a_off[b]);
+                    if (la <= 16 && lb <= 16) return la < lb;          // equal padded prefixes: the shorter string sorts first
+                    return view(a) < view(b);
+                };
+                {
+                    unsigned nt = std::thread::hardware_concurrency();
+                    if (const char* env = getenv("BLU_INGEST_THREADS")) nt = (unsigned)atoi(env);
+                    nt = std::max(1u, std::min(nt, 32u));
+                    if (n_acc < 65536) nt = 1;
+                    std::vector<std::thread> pool;
+                    for (unsigned t = 0; t < nt; ++t)
+                        pool.emplace_back([&, t]() { std::sort(order.begin() + (size_t)n_acc * t / nt, order.begin() + (size_t)n_acc * (t + 1) / nt, less); });
+                    for (auto& th : pool) th.join();
+                    for (unsigned w = 1; w < nt; w *= 2)
+                        for (unsigned t = 0; t + w < nt; t += 2 * w)
+                            std::inplace_merge(order.begin() + (size_t)n_acc * t / nt, order.begin() + (size_t)n_acc * (t + w) / nt,
+                                               order.begin() + (size_t)n_acc * std::min(t + 2 * w, nt) / nt, less);
+                }
+            } catch (...) { acc_sort_failed = true; }   // (no exception leaves a std::thread)
+        });
+    }
+
     // ---- query dictionary: sized by the number of runs of equal hashes (an upper bound of the distinct count)
     {
         hipLaunchKernelGGL(count_run_heads, grid(n_rows, 1024), dim3(1024), 0, 0, d_qh, n_rows, d_big + 1);
@@ -830,81 +914,17 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     }
     lap("query dictionary");
 
-    // ---- accession dictionary: distinct count unknown; the table grows until the load stays under one half
+    // ---- accession dictionary, second half: the ranks go up, every row gets its accession's
     {
-        uint64_t cap = pow2_at_least(std::min<uint64_t>((uint64_t)n_rows * 2 + 16, 1ull << 20));   // (32 MB: stays in the caches while 100 M rows probe it; x4 when more than half full)
-        for (;;) {
-            HIPCHK(mem.alloc((void**)&d_atab, cap * sizeof(Slot)));
-            lap("  acc: table allocation");
-            hipLaunchKernelGGL(dict_init, grid(cap), dim3(256), 0, 0, d_atab, cap);
-            HIPCHK(hipMemset(d_counter, 0, 4));
-            HIPCHK(hipMemset(d_flags, 0, 4));
-            hipLaunchKernelGGL(dict_insert, grid(n_rows), dim3(256), 0, 0, d_ah, n_rows, d_atab, cap - 1, false, d_counter, d_flags);
-            hipLaunchKernelGGL(dict_count, grid(cap, 1024), dim3(1024), 0, 0, d_atab, cap, d_counter);
-            HIPCHK(hipMemcpy(&n_acc, d_counter, 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
-            if (!(h_flags & FB_TABLE_FULL) && (uint64_t)n_acc * 2 <= cap) break;
-            mem.free(d_atab); d_atab = nullptr;
-            if (cap >= pow2_at_least((uint64_t)n_rows * 2 + 16)) { rc = fallback(fallback_text(FB_TABLE_FULL)); goto done; }
-            cap *= 4;
-        }
-        lap("  acc: insert");
-        HIPCHK(hipMemset(d_flags, 0, 4));
-        HIPCHK(mem.alloc((void**)&d_list_row, (size_t)n_acc * 4)); HIPCHK(mem.alloc((void**)&d_list_slot, (size_t)n_acc * 4));
-        HIPCHK(hipMemset(d_counter, 0, 4));
-        hipLaunchKernelGGL(dict_finalize, grid(cap), dim3(256), 0, 0, d_atab, cap, d_text, d_apos, d_list_row, d_list_slot, d_counter);
-        HIPCHK(mem.alloc((void**)&d_poslist, (size_t)n_acc * 8));
-        hipLaunchKernelGGL(gather_pos, grid(n_acc), dim3(256), 0, 0, d_apos, d_list_row, n_acc, d_poslist);
-        rc = download_strings(d_poslist, n_acc, a_bytes, a_off);
-        if (rc != BLU_OK) goto done;
-        lap("  acc: distinct to host");
-        // byte order of the distinct accessions (String::cmp), on the host: only the distinct strings are touched, and
-        // mostly not even those — the GPU hands over their first 16 bytes as two big-endian integers; the text is read
-        // only to order keys that agree on all 16
-        std::vector<unsigned long long> k0(n_acc), k1(n_acc);
-        {
-            unsigned long long *d_k0 = nullptr, *d_k1 = nullptr;
-            HIPCHK(mem.alloc((void**)&d_k0, (size_t)n_acc * 8 + 8));
-            hipError_t e2 = mem.alloc((void**)&d_k1, (size_t)n_acc * 8 + 8);
-            if (e2 == hipSuccess) {
-                hipLaunchKernelGGL(gather_key16, grid(n_acc), dim3(256), 0, 0, d_poslist, n_acc, d_text, d_k0, d_k1);
-                e2 = hipMemcpy(k0.data(), d_k0, (size_t)n_acc * 8, hipMemcpyDeviceToHost);
-                if (e2 == hipSuccess) e2 = hipMemcpy(k1.data(), d_k1, (size_t)n_acc * 8, hipMemcpyDeviceToHost);
-            }
-            mem.free(d_k0);
-            mem.free(d_k1);
-            HIPCHK(e2);
-        }
-        order.resize(n_acc);
-        for (uint32_t k = 0; k < n_acc; ++k) order[k] = k;
-        auto view = [&](uint32_t k) { return std::string_view(a_bytes.data() + a_off[k], (size_t)(a_off[k + 1] - a_off[k])); };
-        auto less = [&](uint32_t a, uint32_t b) {
-            if (k0[a] != k0[b]) return k0[a] < k0[b];
-            if (k1[a] != k1[b]) return k1[a] < k1[b];
-            const size_t la = (size_t)(a_off[a + 1] - a_off[a]), lb = (size_t)(a_off[b + 1] - a_off[b]);
-            if (la <= 16 && lb <= 16) return la < lb;          // equal padded prefixes: the shorter string sorts first
-            return view(a) < view(b);
-        };
-        {
-            unsigned nt = std::thread::hardware_concurrency();
-            if (const char* env = getenv("BLU_INGEST_THREADS")) nt = (unsigned)atoi(env);
-            nt = std::max(1u, std::min(nt, 32u));
-            if (n_acc < 65536) nt = 1;
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t < nt; ++t)
-                pool.emplace_back([&, t]() { std::sort(order.begin() + (size_t)n_acc * t / nt, order.begin() + (size_t)n_acc * (t + 1) / nt, less); });
-            for (auto& th : pool) th.join();
-            for (unsigned w = 1; w < nt; w *= 2)
-                for (unsigned t = 0; t + w < nt; t += 2 * w)
-                    std::inplace_merge(order.begin() + (size_t)n_acc * t / nt, order.begin() + (size_t)n_acc * (t + w) / nt,
-                                       order.begin() + (size_t)n_acc * std::min(t + 2 * w, nt) / nt, less);
-        }
-        lap("  acc: host sort");
+        acc_sort.join();
+        if (acc_sort_failed) { rc = fallback("the host could not sort the accessions"); goto done; }
+        lap("  acc: wait for the host sort");
+        const uint64_t cap = acap;
         std::vector<uint32_t> rank_of(n_acc);
         for (uint32_t r = 0; r < n_acc; ++r) rank_of[order[r]] = r;
         HIPCHK(mem.alloc((void**)&d_ranks, (size_t)n_acc * 4));
         HIPCHK(hipMemcpy(d_ranks, rank_of.data(), (size_t)n_acc * 4, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(dict_assign_ids, grid(n_acc), dim3(256), 0, 0, d_atab, d_list_slot, (const uint32_t*)d_ranks, n_acc);
+        hipLaunchKernelGGL(dict_assign_ids, grid(n_acc), dim3(256), 0, 0, d_atab, d_alist_slot, (const uint32_t*)d_ranks, n_acc);
         HIPCHK(mem.alloc((void**)&d_arank, (size_t)n_rows * 4));
         hipLaunchKernelGGL(dict_lookup, grid(n_rows), dim3(256), 0, 0, d_ah, d_apos, n_rows, d_atab, cap - 1, d_text, d_apos, d_arank, d_flags);
         HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
@@ -968,8 +988,7 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
         }
         // the host strings (query names in id order, accessions in byte order) are built from the packed bytes by a
         // background thread while the caller goes on to the engine: nothing on the device waits for them
-        ht.query_names.resize(n_queries);
-        ht.accessions.resize(n_acc);
+        ht.n_queries = n_queries;
         unsigned nt = std::thread::hardware_concurrency();
         if (const char* env = getenv("BLU_INGEST_THREADS")) nt = (unsigned)atoi(env);
         nt = std::max(1u, std::min(nt, 16u));
@@ -978,6 +997,9 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
         ht.strings_thread = std::thread([hp, nt, q_bytes = std::move(q_bytes), q_off = std::move(q_off), a_bytes = std::move(a_bytes),
                                          a_off = std::move(a_off), order = std::move(order)]() {
             std::atomic<bool> oom{false};            // (an exception must not leave a std::thread: the caller checks strings_ok)
+            // (sizing 2 M strings is 64 MB of fresh pages: 10 ms that need not stand between the ingest and the engine)
+            try { hp->query_names.resize(q_off.size() - 1); hp->accessions.resize(a_off.size() - 1); }
+            catch (const std::bad_alloc&) { hp->strings_ok = false; return; }
             auto work = [&](unsigned t) {
                 try {
                     const size_t nq = q_off.size() - 1, na = a_off.size() - 1;

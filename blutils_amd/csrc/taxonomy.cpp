@@ -500,40 +500,37 @@ int blu_taxonomy_create(const blu_taxonomy_desc* desc, const blu_cutoff_config* 
         hipDeviceProp_t prop;
         if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
         if (e == hipSuccess) tax->num_cus = prop.multiProcessorCount;
-        size_t b_lin = dev_rows.size() * sizeof(uint32_t);
-        size_t b_cut = cutvals.size() * sizeof(double);
-        size_t b_codes = dev_codes.size() * sizeof(uint32_t);
-        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lin, b_lin);
-        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_lcp8, lcp8.size());
-        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_rmq, rmq.size());
-        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_cutvals, b_cut);
-        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_codes, b_codes);
-        if (e == hipSuccess) e = hipMemcpy(tax->d_codes, dev_codes.data(), b_codes, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_kthr, b_codes);
-        if (e == hipSuccess) e = hipMemcpy(tax->d_kthr, dev_kthr.data(), b_codes, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(tax->d_lin, dev_rows.data(), b_lin, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(tax->d_lcp8, lcp8.data(), lcp8.size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(tax->d_rmq, rmq.data(), rmq.size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(tax->d_cutvals, cutvals.data(), b_cut, hipMemcpyHostToDevice);
-        if (wide_ok && !wblk.empty()) {
-            if (e == hipSuccess) e = hipMalloc((void**)&tax->d_wblk, wblk.size() * sizeof(uint2));
-            if (e == hipSuccess) e = hipMemcpy(tax->d_wblk, wblk.data(), wblk.size() * sizeof(uint2), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMalloc((void**)&tax->d_wchain, wchain.size() * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMemcpy(tax->d_wchain, wchain.data(), wchain.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            if (!wchain_hi.empty()) {
-                if (e == hipSuccess) e = hipMalloc((void**)&tax->d_wchain_hi, wchain_hi.size() * sizeof(uint32_t));
-                if (e == hipSuccess) e = hipMemcpy(tax->d_wchain_hi, wchain_hi.data(), wchain_hi.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            }
+        // every table in ONE allocation (256-byte aligned pieces): one hipMalloc at creation, one hipFree at the end
+        struct Part { void** view; const void* src; size_t bytes; size_t at; };
+        const bool wide_tables = wide_ok && !wblk.empty();
+        std::vector<Part> parts = {
+            {(void**)&tax->d_lin, dev_rows.data(), dev_rows.size() * sizeof(uint32_t), 0},
+            {(void**)&tax->d_lcp8, lcp8.data(), lcp8.size(), 0},
+            {(void**)&tax->d_rmq, rmq.data(), rmq.size(), 0},
+            {(void**)&tax->d_cutvals, cutvals.data(), cutvals.size() * sizeof(double), 0},
+            {(void**)&tax->d_codes, dev_codes.data(), dev_codes.size() * sizeof(uint32_t), 0},
+            {(void**)&tax->d_kthr, dev_kthr.data(), dev_codes.size() * sizeof(uint32_t), 0},
+            {(void**)&tax->d_hint_of_pos, tax->hint_of_pos.data(), tax->hint_of_pos.size() * sizeof(uint16_t), 0},
+        };
+        if (wide_tables) {
+            parts.push_back({(void**)&tax->d_wblk, wblk.data(), wblk.size() * sizeof(uint2), 0});
+            parts.push_back({(void**)&tax->d_wchain, wchain.data(), wchain.size() * sizeof(uint32_t), 0});
+            if (!wchain_hi.empty()) parts.push_back({(void**)&tax->d_wchain_hi, wchain_hi.data(), wchain_hi.size() * sizeof(uint32_t), 0});
         }
-        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_hint_of_pos, tax->hint_of_pos.size() * sizeof(uint16_t));
-        if (e == hipSuccess) e = hipMemcpy(tax->d_hint_of_pos, tax->hint_of_pos.data(), tax->hint_of_pos.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+        size_t total = 0, payload = 0;
+        for (Part& p : parts) { p.at = total; total += (std::max<size_t>(p.bytes, 1) + 255) & ~(size_t)255; payload += p.bytes; }
+        if (e == hipSuccess) e = hipMalloc((void**)&tax->d_block, total);
+        for (Part& p : parts) {
+            if (e != hipSuccess) break;
+            *p.view = tax->d_block + p.at;
+            if (p.bytes) e = hipMemcpy(*p.view, p.src, p.bytes, hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess) {
             set_error("HIP error while uploading the taxonomy: %s", hipGetErrorString(e));
             blu_taxonomy_destroy(tax);
             return BLU_ERR_HIP;
         }
-        tax->device_bytes = b_lin + lcp8.size() + rmq.size() + b_cut + 2 * b_codes + tax->hint_of_pos.size() * sizeof(uint16_t) +
-                            (tax->d_wblk ? wblk.size() * sizeof(uint2) + (wchain.size() + wchain_hi.size()) * sizeof(uint32_t) : 0);
+        tax->device_bytes = payload;
     }
     *out = tax;
     return BLU_OK;
@@ -543,16 +540,7 @@ void blu_taxonomy_destroy(blu_taxonomy* tax) {
     if (!tax) return;
     if (tax->device >= 0) {
         (void)hipSetDevice(tax->device);
-        if (tax->d_lin) (void)hipFree(tax->d_lin);
-        if (tax->d_lcp8) (void)hipFree(tax->d_lcp8);
-        if (tax->d_rmq) (void)hipFree(tax->d_rmq);
-        if (tax->d_wblk) (void)hipFree(tax->d_wblk);
-        if (tax->d_wchain) (void)hipFree(tax->d_wchain);
-        if (tax->d_wchain_hi) (void)hipFree(tax->d_wchain_hi);
-        if (tax->d_cutvals) (void)hipFree(tax->d_cutvals);
-        if (tax->d_codes) (void)hipFree(tax->d_codes);
-        if (tax->d_kthr) (void)hipFree(tax->d_kthr);
-        if (tax->d_hint_of_pos) (void)hipFree(tax->d_hint_of_pos);
+        if (tax->d_block) (void)hipFree(tax->d_block);      // (d_lin ... d_wchain_hi are views into it)
         if (tax->ws_worklist) (void)hipFree(tax->ws_worklist);
         if (tax->ws_count) (void)hipFree(tax->ws_count);
         if (tax->ws_pack_flag) (void)hipFree(tax->ws_pack_flag);

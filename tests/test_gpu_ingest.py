@@ -31,10 +31,12 @@ def _db(tmp_path, n=3000):
     return str(tj)
 
 
-def _rows(n_q, hits, rng, long_names=False):
+def _rows(n_q, hits, rng, long_names=False, long_lines=False):
     rows = []
     for q in range(n_q):
         name = f"query_with_a_rather_long_identifier_{q:07d}/1" if long_names else f"q{q:06d}"
+        if long_lines and (q // 500) % 2:      # stretches of 300-byte lines: their 256-line blocks do not fit the parse kernel's
+            name = f"q{q:06d}_" + "x" * 260    # LDS stage and take its general form; the accessions are shared with the others
         for j in range(int(rng.integers(1, hits + 1))):
             t = int(rng.integers(0, 3100))                       # some taxids are not in the DB
             bs = int(rng.integers(50, 200000))
@@ -52,10 +54,10 @@ def _both(bt, tj):
     return cpu_stats, cpu_ck, gpu_stats, gpu_ck, pipeline.last_ingest_path()
 
 
-@pytest.mark.parametrize("layout", ["grouped", "scrambled", "crlf_no_final_newline", "long_names"])
+@pytest.mark.parametrize("layout", ["grouped", "scrambled", "crlf_no_final_newline", "long_names", "long_lines"])
 def test_gpu_ingest_gives_the_cpu_columns(tmp_path, force_gpu, layout):
     rng = np.random.default_rng(5)
-    rows = _rows(6000, 12, rng, long_names=layout == "long_names")
+    rows = _rows(6000, 12, rng, long_names=layout == "long_names", long_lines=layout == "long_lines")
     if layout == "scrambled":       # rows of one query need not be contiguous; their relative order must survive
         order = sorted(range(len(rows)), key=lambda i: (int(rng.integers(0, 4)), i))
         rows = [rows[i] for i in order]
@@ -158,13 +160,18 @@ def _assert_columns_equal(got, exp):
     assert got["query_names"] == exp["query_names"] and got["accessions"] == exp["accessions"]
 
 
+@pytest.mark.parametrize("form", ["staged", "general"])
 @pytest.mark.parametrize("eol", ["lf", "crlf", "crlf_no_final_newline"])
-def test_gpu_parser_against_an_independent_reading(tmp_path, force_gpu, eol):
+def test_gpu_parser_against_an_independent_reading(tmp_path, force_gpu, eol, form):
     """Every numeric spelling the GPU parser takes (tests/test_ingest.py: grammar_rows), columns compared one by one with
-    tests/ingest_reference.py — Python's float() / int() on str.split fields, the reference's schema (mod.rs:226-244)."""
+    tests/ingest_reference.py — Python's float() / int() on str.split fields, the reference's schema (mod.rs:226-244).
+    form: the parse kernel's LDS-staged form (BLAST's usual line lengths) and its general form (256 lines that do not fit
+    the stage: here a dead column carries 200 bytes of filler)."""
     from tests import ingest_reference as ref
     from tests.test_ingest import grammar_db, grammar_rows
     rows = grammar_rows(True) * 40                    # 1920 rows: several 256-line blocks of the parse kernel
+    if form == "general":
+        rows = ["\t".join(c[:5] + [c[5] + "x" * 200] + c[6:]) for c in (r.split("\t") for r in rows)]
     sep = "\n" if eol == "lf" else "\r\n"
     bt = tmp_path / "g.tsv"
     bt.write_bytes((sep.join(rows) + ("" if eol == "crlf_no_final_newline" else sep)).encode())
@@ -191,11 +198,11 @@ def test_spellings_the_gpu_parser_declines_still_give_the_independent_columns(tm
     _assert_columns_equal(got, ref.read_table(str(bt), tj))
 
 
-@pytest.mark.parametrize("layout", ["scrambled", "long_names"])
+@pytest.mark.parametrize("layout", ["scrambled", "long_names", "long_lines"])
 def test_gpu_parser_columns_of_blast_shaped_tables(tmp_path, force_gpu, layout):
     from tests import ingest_reference as ref
     rng = np.random.default_rng(15)
-    rows = _rows(3000, 9, rng, long_names=layout == "long_names")
+    rows = _rows(3000, 9, rng, long_names=layout == "long_names", long_lines=layout == "long_lines")
     if layout == "scrambled":
         order = sorted(range(len(rows)), key=lambda i: (int(rng.integers(0, 5)), i))
         rows = [rows[i] for i in order]
