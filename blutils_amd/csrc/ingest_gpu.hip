@@ -590,9 +590,12 @@ static int upload_file(int fd, size_t size, unsigned char* d_text, int device, s
     };
     char* block = nullptr;
     std::vector<hipEvent_t> events((size_t)nt * 2, nullptr);
+    const bool trace = getenv("BLU_INGEST_TRACE") != nullptr;
+    const double t_in = now_s();
     hipError_t e0 = hipHostMalloc((void**)&block, (size_t)nt * 2 * piece, hipHostMallocDefault);
     for (size_t k = 0; k < events.size() && e0 == hipSuccess; ++k) e0 = hipEventCreateWithFlags(&events[k], hipEventDisableTiming);
     if (e0 != hipSuccess) fail(nt, "staging set-up", e0);
+    const double t_setup = now_s();
     auto work = [&](unsigned t) {
         char* const slots = block + (size_t)t * 2 * piece;
         hipEvent_t* const ev = &events[(size_t)t * 2];
@@ -626,8 +629,11 @@ static int upload_file(int fd, size_t size, unsigned char* d_text, int device, s
         for (auto& th : pool) th.join();
     }
     {   // the slots are free once everything queued has been sent (also on the way out of a failure: copies may be in flight)
+        const double t_queued = now_s();
         const hipError_t e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess && !failed) fail(nt, "hipStreamSynchronize", e);
+        if (trace) fprintf(stderr, "[ingest-gpu]   upload: pinned block + events %.3f s, pieces read and queued %.3f s, last ones on the wire %.3f s\n",
+                           t_setup - t_in, t_queued - t_setup, now_s() - t_queued);
     }
     for (hipEvent_t ev : events) if (ev) (void)hipEventDestroy(ev);
     if (block) (void)hipHostFree(block);
@@ -737,7 +743,8 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     // ---- upload + line index
     lap("device start-up");
     HIPCHK(mem.alloc((void**)&d_text, size + 64));
-    HIPCHK(hipMemset(d_text + size, 0, 64));   // the padding only (the readers' pieces end at `size`)
+    HIPCHK(hipMemset(d_text + size, 0, 64));
+    lap("  upload: device buffer");   // the padding only (the readers' pieces end at `size`)
     {
         std::string io;
         rc = upload_file(fd, size, d_text, device, &io);

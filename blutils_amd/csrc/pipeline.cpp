@@ -1452,11 +1452,16 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
     }
     st.t_render_s = now_s() - t0;
     if (stats) *stats = st;
-    // the big objects go to the graveyard thread (if it cannot be started they die here, as they would have anyway)
-    try {
-        g_graveyard.bury(std::thread([db_owner = std::move(db_owner), ht_owner = std::move(ht_owner), recs = std::move(recs), top = std::move(top),
-                                      items = std::move(items)]() mutable {}));
-    } catch (...) {}
+    // the big objects and the taxonomy handle (whose 2 GB of packed staging take 25 ms to hipFree) go to the graveyard thread;
+    // if it cannot be started they die here, as they would have anyway
+    {
+        blu_taxonomy* const tax_to_free = tax;
+        tax = nullptr;                                // (tax_guard below finds nothing left to destroy)
+        try {
+            g_graveyard.bury(std::thread([tax_to_free, db_owner = std::move(db_owner), ht_owner = std::move(ht_owner), recs = std::move(recs),
+                                          top = std::move(top), items = std::move(items)]() mutable { blu_taxonomy_destroy(tax_to_free); }));
+        } catch (...) { blu_taxonomy_destroy(tax_to_free); }
+    }
     tr.lap("hand the memory to its thread");
     g_t_body_end = now_s();
     return BLU_OK;
