@@ -485,7 +485,9 @@ __device__ __forceinline__ double pid_f64(typename PidKey<PID32>::type k) {
 #endif
 #define LONG_SPAN (1u << 28)    // rows one bit-score descriptor of the worklist kernel covers
 #ifndef BLU_B_WAVES_PER_SIMD
-#define BLU_B_WAVES_PER_SIMD 8   // worklist kernel: 64 VGPRs, 32 waves per CU (it hides memory round trips with waves, not with registers)
+#define BLU_B_WAVES_PER_SIMD 7   // worklist kernel: 72 VGPRs, 28 waves per CU (it hides memory round trips with waves, not with registers).
+                                 // At 8 (64 VGPRs) every column-layout and cautious build parked 8-20 B per lane in scratch: the same time on
+                                 // C5 relaxed, 12 % slower on C5 cautious (0.471 -> 0.413 ms, scripts/calls/r4_call30.sh)
 #endif
 #define KEEP_ROWS 1024u         // worklist kernel: a segment of up to this many rows is held in registers (4 x 16 bytes per lane)
 #define SLOT_CAP 256u           // worklist kernel: rows of a top group collected before their side records are gathered

@@ -453,7 +453,19 @@ __global__ void dict_lookup(const unsigned long long* __restrict__ h, const unsi
     const uint64_t off = pos[i] & ((1ull << 44) - 1);
     const uint32_t len = (uint32_t)(pos[i] >> 44);
     bool same = len == sl.len;
-    for (uint32_t k = 0; same && k < 12 && k < len; ++k) same = text[off + k] == sl.head[k];
+    {   // the first min(len, 12) bytes against the slot's: ONE unaligned 12-byte load (the text has 64 bytes of padding behind
+        // it; the slot's bytes beyond its length are zero) instead of twelve byte loads with 64 lines each
+        uint32_t w[3], hw[3];
+        __builtin_memcpy(w, text + off, 12);
+        __builtin_memcpy(hw, sl.head, 12);
+        const uint32_t n = len < 12u ? len : 12u;
+#pragma unroll
+        for (uint32_t j = 0; j < 3; ++j) {
+            const uint32_t nb = n > 4 * j ? n - 4 * j : 0u;
+            const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
+            same = same && ((w[j] ^ hw[j]) & m) == 0;
+        }
+    }
     if (same && len > 12 && sl.first_row != i) {
         const uint64_t roff = pos_all[sl.first_row] & ((1ull << 44) - 1);
         for (uint32_t k = 12; same && k < len; ++k) same = text[off + k] == text[roff + k];
