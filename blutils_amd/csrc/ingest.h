@@ -79,6 +79,7 @@ struct DeviceHits {
     double* pident = nullptr;
     unsigned long long* seg_off = nullptr;   // [n_queries + 1]
     void* seg_block = nullptr;               // allocation seg_off lives in
+    std::vector<void*> trash;                // device work buffers of device_run_consensus: freed with the columns (a hipFree is 1-2 ms)
     ~DeviceHits();
 };
 

@@ -1045,11 +1045,40 @@ done:
         ht.clear();
     }
     lap("hand-over");
+    // with room on the card (mem.keep) the work buffers — the text, the hashes, the dictionaries: 10 GB for a 2 M-query table —
+    // are freed with the columns, off the caller's path (5-7 ms of hipFree); otherwise here
+    if (rc == BLU_OK && mem.keep && ht.dev) { ht.dev->trash.insert(ht.dev->trash.end(), mem.ptrs.begin(), mem.ptrs.end()); mem.ptrs.clear(); }
     mem.free_all();
     lap("free the work buffers");
     return rc;
 }
 
+
+// Device -> pageable host memory in 8 MiB pieces by a pool of host threads: the first touch of the fresh destination pages
+// (and the runtime's pinning of them) costs more than the transfer, and it parallelises.
+struct D2HPiece { char* dst; const char* src; size_t bytes; };
+static void d2h_add(std::vector<D2HPiece>& v, void* dst, const void* src, size_t bytes, size_t piece = 8u << 20) {
+    for (size_t o = 0; o < bytes; o += piece) v.push_back({(char*)dst + o, (const char*)src + o, std::min(piece, bytes - o)});
+}
+static hipError_t d2h_parallel(const std::vector<D2HPiece>& pieces, int device, unsigned max_threads = 16) {
+    if (pieces.empty()) return hipSuccess;
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char* env = getenv("BLU_INGEST_THREADS")) nt = (unsigned)atoi(env);
+    nt = std::max(1u, std::min<unsigned>(std::min(nt, max_threads), (unsigned)pieces.size()));
+    std::vector<hipError_t> errs(nt, hipSuccess);
+    std::atomic<size_t> next{0};
+    auto work = [&](unsigned t) {
+        (void)hipSetDevice(device);
+        for (size_t k = next.fetch_add(1); k < pieces.size() && errs[t] == hipSuccess; k = next.fetch_add(1))
+            errs[t] = hipMemcpy(pieces[k].dst, pieces[k].src, pieces[k].bytes, hipMemcpyDeviceToHost);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    for (hipError_t e : errs) if (e != hipSuccess) return e;
+    return hipSuccess;
+}
 
 // The columns come back in 64 MiB pieces copied by a pool of host threads: the first touch of the fresh host pages
 // costs more than the transfer, and it parallelises (the vectors are resized without initialisation).
@@ -1060,32 +1089,15 @@ int download_columns(HitTable& ht) {
     const size_t n_rows = d.n_hits, n_queries = d.n_queries;
     ht.seg_off.resize(n_queries + 1);
     ht.bitscore.resize(n_rows); ht.align_len.resize(n_rows); ht.tax_desc_row.resize(n_rows); ht.acc_rank.resize(n_rows); ht.pident.resize(n_rows);
-    struct Piece { char* dst; const char* src; size_t bytes; };
-    std::vector<Piece> pieces;
-    auto add = [&](void* dst, const void* src, size_t bytes) {
-        for (size_t o = 0; o < bytes; o += (64u << 20)) pieces.push_back({(char*)dst + o, (const char*)src + o, std::min<size_t>(64u << 20, bytes - o)});
-    };
+    std::vector<D2HPiece> pieces;
+    auto add = [&](void* dst, const void* src, size_t bytes) { d2h_add(pieces, dst, src, bytes, 64u << 20); };
     add(ht.seg_off.data(), d.seg_off, (n_queries + 1) * 8);
     add(ht.bitscore.data(), d.bitscore, n_rows * 4); add(ht.align_len.data(), d.align_len, n_rows * 4);
     add(ht.tax_desc_row.data(), d.tax_desc_row, n_rows * 4); add(ht.acc_rank.data(), d.acc_rank, n_rows * 4);
     add(ht.pident.data(), d.pident, n_rows * 8);
-    unsigned nt = std::thread::hardware_concurrency();
-    if (const char* env = getenv("BLU_INGEST_THREADS")) nt = (unsigned)atoi(env);
-    nt = std::max(1u, std::min<unsigned>(std::min(nt, 16u), (unsigned)pieces.size()));
-    std::vector<hipError_t> errs(nt, hipSuccess);
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> pool;
-    const int device = d.device;
-    for (unsigned t = 0; t < nt; ++t)
-        pool.emplace_back([&, t]() {
-            (void)hipSetDevice(device);
-            // (pinning the destination pieces first — hipHostRegister — made it slower: 0.33 s instead of 0.21 s for 2 GB)
-            for (size_t k = next.fetch_add(1); k < pieces.size() && errs[t] == hipSuccess; k = next.fetch_add(1))
-                errs[t] = hipMemcpy(pieces[k].dst, pieces[k].src, pieces[k].bytes, hipMemcpyDeviceToHost);
-        });
-    for (auto& th : pool) th.join();
-    for (hipError_t e : errs)
-        if (e != hipSuccess) { set_error("GPU ingest: column download failed: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
+    // (pinning the destination pieces first — hipHostRegister — made it slower: 0.33 s instead of 0.21 s for 2 GB)
+    const hipError_t e = d2h_parallel(pieces, d.device);
+    if (e != hipSuccess) { set_error("GPU ingest: column download failed: %s", hipGetErrorString(e)); return BLU_ERR_HIP; }
     ht.host_columns = true;
     return BLU_OK;
 }
@@ -1180,6 +1192,7 @@ DeviceHits::~DeviceHits() {
     (void)hipSetDevice(device);
     for (void* p : {(void*)bitscore, (void*)align_len, (void*)tax_desc_row, (void*)acc_rank, (void*)pident, seg_block})
         if (p) (void)hipFree(p);
+    for (void* p : trash) (void)hipFree(p);
 }
 
 int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_t* fwd, uint64_t n_tax, int strategy, blu_result* out,
@@ -1234,9 +1247,13 @@ int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_
         rc = blu_consensus_run(tax, &h, &rp, d_out);
         if (rc != BLU_OK) goto done;
     }
-    HIPCHK(hipMemcpy(out, d_out, nq * sizeof(blu_result), hipMemcpyDeviceToHost));   // waits for the null stream
+    HIPCHK(hipStreamSynchronize(nullptr));
+    {
+        std::vector<D2HPiece> pieces;
+        d2h_add(pieces, out, d_out, nq * sizeof(blu_result));
+        HIPCHK(d2h_parallel(pieces, dev.device));
+    }
     if (top) {
-        if (d_rec) { (void)hipFree(d_rec); d_rec = nullptr; }
         const uint64_t waves = (nq + TOP_QPW - 1) / TOP_QPW;
         const dim3 g((unsigned)((waves * 64 + 255) / 256));
         HIPCHK(hipMalloc((void**)&d_cnt, (nq + 1) * 8 * 2));
@@ -1256,13 +1273,17 @@ int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_
                                    dev.tax_desc_row, dev.acc_rank, dev.align_len, dev.pident, d_top, d_score);
         top->rows.resize(n_top);
         top->score.resize(nq);
-        HIPCHK(hipMemcpy(top->rows.data(), d_top, n_top * sizeof(TopRow), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(top->score.data(), d_score, nq * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipStreamSynchronize(nullptr));
+        std::vector<D2HPiece> pieces;
+        d2h_add(pieces, top->rows.data(), d_top, n_top * sizeof(TopRow));
+        d2h_add(pieces, top->score.data(), d_score, nq * 4);
+        HIPCHK(d2h_parallel(pieces, dev.device));
     }
 done:
+    // the work buffers are freed with the columns (DeviceHits::trash): ten hipFree calls were 10-15 ms of this function
     for (void* p : {(void*)d_fwd, (void*)d_milli, (void*)d_rows, (void*)d_flag, (void*)d_out, (void*)d_rec, (void*)d_cnt, d_tmp, (void*)d_top,
                     (void*)d_score})
-        if (p) (void)hipFree(p);
+        if (p) dev.trash.push_back(p);
     return rc;
 }
 

@@ -1047,7 +1047,7 @@ struct Renderer {
 
 // TopTable from host columns (the CPU ingest, or the staging path of the engine): same content as the device-side
 // compaction in ingest_gpu.hip
-void top_rows_from_columns(const HitTable& ht, const std::vector<blu_result>& recs, unsigned nthreads, TopTable& top) {
+void top_rows_from_columns(const HitTable& ht, const Column<blu_result>& recs, unsigned nthreads, TopTable& top) {
     const size_t nq = recs.size();
     top.off.resize(nq + 1);
     top.score.resize(nq);
@@ -1214,7 +1214,8 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
     if (tax_rc != BLU_OK) { set_error("%s", tax_err.c_str()); return tax_rc; }
     if (tr.on) fprintf(stderr, "[pipeline] (taxonomy create, 2nd thread %.3f s)\n", t_tax);
     tr.lap("wait for the taxonomy");
-    std::vector<blu_result> recs(ht.n_queries);
+    Column<blu_result> recs;                      // (not zero-filled: the engine writes every record; the fresh pages are touched by
+    recs.resize(ht.n_queries);                    //  the threads that copy the records back)
     TopTable top;
     bool done_on_device = false;
     // (BLU_PIPELINE_HOST_COLUMNS=1, tests: take the fallback below although the device path would work)
@@ -1227,7 +1228,8 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
         done_on_device = device_run_consensus(tax, *ht.dev, fwd.data(), db.taxid.size(), params->strategy, recs.data(), &top) == BLU_OK;   // mod.rs:104-128
         if (!done_on_device) { rc = download_columns(ht); if (rc != BLU_OK) return rc; }
     }
-    ht.dev.reset();
+    // (the device columns and the engine's work buffers stay with the hit table: they are freed off the caller's path at the end)
+    if (!done_on_device) ht.dev.reset();
     if (!done_on_device) {
         std::vector<uint32_t> eng_rows(ht.tax_desc_row.size());
         for (size_t i = 0; i < eng_rows.size(); ++i)
