@@ -53,6 +53,7 @@ struct Graveyard {
     std::mutex mu;
     std::thread t;
     void bury(std::thread&& next) { std::lock_guard<std::mutex> lk(mu); if (t.joinable()) t.join(); t = std::move(next); }
+    void drain() { std::lock_guard<std::mutex> lk(mu); if (t.joinable()) t.join(); }
     ~Graveyard() { if (t.joinable()) t.join(); }
 };
 Graveyard g_graveyard;
@@ -1155,6 +1156,7 @@ int build_document(const char* blast_output_file, const char* const* headers, ui
     blu_pipeline_stats st{};
     Trace tr;
     const unsigned nthreads = worker_threads();
+    g_graveyard.drain();   // (a previous call's memory — device memory too — is back before this one sizes itself against what is free)
     double t0 = now_s();
     // (HIP start-up beside the reading of the taxonomy file; BLU_INGEST=cpu callers with no device never get here with one)
     std::thread warm_up;
