@@ -157,16 +157,23 @@ def stream_read_ceiling(torch, gib: float = 4.0):
     sink = torch.zeros(4, dtype=torch.int32, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
     best = 0.0
-    for grid in (2048, 4096, 8192):
+    shapes = [(L.probe_read, g) for g in (2048, 4096, 8192)]
+    if hasattr(L, "probe_read_plain"):           # (512-thread blocks, one load per thread and step)
+        L.probe_read_plain.argtypes = L.probe_read.argtypes
+        shapes += [(L.probe_read_plain, g) for g in (1024, 2048, 4096)]
+    for fn, grid in shapes:
         for _ in range(2):
-            L.probe_read(buf.data_ptr(), nbytes, sink.data_ptr(), grid, s)
+            fn(buf.data_ptr(), nbytes, sink.data_ptr(), grid, s)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(5):
-            L.probe_read(buf.data_ptr(), nbytes, sink.data_ptr(), grid, s)
+            fn(buf.data_ptr(), nbytes, sink.data_ptr(), grid, s)
         b.record()
         torch.cuda.synchronize()
-        best = max(best, nbytes * 5 / (a.elapsed_time(b) * 1e-3) / 1e9)
+        rate = nbytes * 5 / (a.elapsed_time(b) * 1e-3) / 1e9
+        if os.environ.get("BLU_BENCH_CEILING_TRACE"):
+            log(f"[bench]   ceiling probe {fn.__name__} grid {grid}: {rate:.0f} GB/s")
+        best = max(best, rate)
     del buf
     torch.cuda.empty_cache()
     return best

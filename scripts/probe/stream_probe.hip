@@ -17,6 +17,22 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const u32x4* __restrict
     if (acc == 0x12345678u) *sink = acc;   // keeps the loads alive, practically never stores
 }
 
+// the plainest shape: 512-thread blocks, one 16-byte load per thread and step (on some boxes this reads 3-6 % faster than the
+// four-deep loop above; bench.py quotes the best of all shapes as the ceiling)
+__global__ __launch_bounds__(512) void probe_read_plain_kernel(const u32x4* __restrict__ p, uint64_t n16, uint32_t* __restrict__ sink) {
+    uint32_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+        const u32x4 v = __builtin_nontemporal_load(p + i);
+        acc ^= v.x ^ v.w;
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
+extern "C" int probe_read_plain(const void* p, uint64_t bytes, void* sink, int grid, void* stream) {
+    hipLaunchKernelGGL(probe_read_plain_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, (const u32x4*)p, bytes / 16, (uint32_t*)sink);
+    return (int)hipGetLastError();
+}
+
 extern "C" int probe_read(const void* p, uint64_t bytes, void* sink, int grid, void* stream) {
     hipLaunchKernelGGL(probe_read_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4*)p, bytes / 16, (uint32_t*)sink);
     return (int)hipGetLastError();
