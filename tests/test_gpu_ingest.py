@@ -74,6 +74,36 @@ def test_gpu_ingest_gives_the_cpu_columns(tmp_path, force_gpu, layout):
     assert gs["n_hits"] == len(rows) and gs["n_queries"] == 6000 and gs["n_unmatched_rows"] > 0
 
 
+@pytest.fixture(scope="module")
+def big_table(tmp_path_factory):
+    rng = np.random.default_rng(21)
+    rows = _rows(40000, 20, rng, long_names=True)
+    d = tmp_path_factory.mktemp("big")
+    bt = d / "b.tsv"
+    bt.write_bytes(("\n".join(rows) + "\n").encode())
+    assert bt.stat().st_size > 5 * (8 << 20)
+    cs, cck = pipeline.ingest_only(str(bt), _db(d), False, device=-1)
+    return str(bt), _db(d), len(rows), cs, cck
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "5"])
+def test_a_table_uploaded_in_many_pieces(big_table, force_gpu, threads):
+    """50 MB of text: six 8 MiB pieces through the pinned staging slots (each reader thread reuses its two slots, so a slot's
+    event is waited for), with one, three and five reader threads; the columns are the CPU parser's."""
+    bt, tj, n_rows, cs, cck = big_table
+    old = os.environ.get("BLU_UPLOAD_THREADS")
+    os.environ["BLU_UPLOAD_THREADS"] = threads
+    try:
+        gs, gck = pipeline.ingest_only(bt, tj, False, device=0)
+    finally:
+        if old is None:
+            os.environ.pop("BLU_UPLOAD_THREADS", None)
+        else:
+            os.environ["BLU_UPLOAD_THREADS"] = old
+    assert pipeline.last_ingest_path() == "gpu" and gck == cck
+    assert gs["n_hits"] == cs["n_hits"] == n_rows and gs["n_queries"] == 40000
+
+
 @pytest.mark.parametrize("case", ["quoted", "empty_line", "many_digits"])
 def test_files_outside_the_gpu_form_take_the_cpu_path(tmp_path, force_gpu, case):
     rng = np.random.default_rng(6)
