@@ -24,13 +24,12 @@
 //                      query / accession strings come back packed and a background thread turns them into the host
 //                      tables; after the engine, top_rows_kernel compacts the top-score rows of the rendered queries —
 //                      all the writer reads of the table
-// The device-wide exclusive scans and the two stable radix sorts of the bookkeeping are rocPRIM's (AMD's own primitives,
-// called directly: no CUB-API layer); block-level sums and scans are the wave-level DPP / LDS code below; the parsing and
-// dictionary kernels are written here.  HBM-bound byte work: no MFMA.
+// The two stable radix sorts of the bookkeeping (distinct queries by first row; rows by query id when the file is not grouped)
+// are rocPRIM's (AMD's own primitives, called directly: no CUB-API layer); everything else — the device-wide prefix sums,
+// block-level sums and scans, the parsing and dictionary kernels — is written here.  HBM-bound byte work: no MFMA.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 #include <unistd.h>
 
 #include <algorithm>
@@ -112,6 +111,83 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wave_s
     for (int w = 0; w < THREADS / 64; ++w) before += (uint32_t)w < wave ? wave_sums[w] : 0u;
     __syncthreads();
     return before + incl - v;
+}
+
+// ---- device-wide exclusive prefix sum (u32 / u64), three launches: sums of 4096-element blocks, a one-block scan of those sums,
+// the blocks again with their offsets.  The arrays scanned here are bookkeeping (newline counts per 4 KiB tile, string lengths,
+// top-row counts: 2 M elements at most per 100 M rows), so reading them twice costs microseconds; written here rather than
+// taken from a library so that the ingest's device code is the kernels in this file plus two radix sorts.
+constexpr int SCAN_THREADS = 1024, SCAN_ITEMS = 4, SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;
+
+template <class T>
+__device__ __forceinline__ T wave_incl_scan_t(T v) {
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) { const T u = __shfl_up(v, d); if (lane >= d) v += u; }
+    return v;
+}
+// exclusive prefix of v over the 1024 threads of the block, and the block's total; `wave_tot` = LDS, 16 entries
+template <class T>
+__device__ __forceinline__ T block_excl_scan_t(T v, T* wave_tot, T* total) {
+    const T incl = wave_incl_scan_t(v);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    T before = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < SCAN_THREADS / 64; ++w) { const T x = wave_tot[w]; all += x; if (w < wave) before += x; }
+    __syncthreads();
+    *total = all;
+    return before + incl - v;
+}
+template <class T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums(const T* __restrict__ in, size_t n, T* __restrict__ block_sum) {
+    __shared__ T wave_tot[SCAN_THREADS / 64];
+    const size_t base = ((size_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
+    T v = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n) v += in[base + k];
+    T total;
+    (void)block_excl_scan_t(v, wave_tot, &total);
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+}
+template <class T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_offsets(const T* __restrict__ block_sum, size_t n_blocks, T* __restrict__ block_off) {
+    __shared__ T wave_tot[SCAN_THREADS / 64];
+    T carry = 0;
+    for (size_t b0 = 0; b0 < n_blocks; b0 += SCAN_THREADS) {        // (one block: the sums of 4096-element blocks are few)
+        const size_t b = b0 + threadIdx.x;
+        const T v = b < n_blocks ? block_sum[b] : (T)0;
+        T total;
+        const T ex = block_excl_scan_t(v, wave_tot, &total);
+        if (b < n_blocks) block_off[b] = carry + ex;
+        carry += total;
+    }
+}
+template <class T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply(const T* __restrict__ in, size_t n, const T* __restrict__ block_off, T* __restrict__ out) {
+    __shared__ T wave_tot[SCAN_THREADS / 64];
+    const size_t base = ((size_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
+    T x[SCAN_ITEMS], v = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { x[k] = base + k < n ? in[base + k] : (T)0; v += x[k]; }
+    T total;
+    T run = block_off[blockIdx.x] + block_excl_scan_t(v, wave_tot, &total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < n) out[base + k] = run; run += x[k]; }
+}
+template <class T> size_t scan_tmp_bytes(size_t n) { return 2 * ((n + SCAN_BLOCK - 1) / SCAN_BLOCK) * sizeof(T) + 16; }
+// out[i] = in[0] + ... + in[i - 1] for i < n (in and out distinct); tmp: scan_tmp_bytes<T>(n) bytes of device memory
+template <class T>
+hipError_t exclusive_scan_dev(const T* in, T* out, size_t n, void* tmp) {
+    if (n == 0) return hipSuccess;
+    const size_t n_blocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    T* const block_sum = (T*)tmp;
+    T* const block_off = block_sum + n_blocks;
+    hipLaunchKernelGGL((scan_block_sums<T>), dim3((unsigned)n_blocks), dim3(SCAN_THREADS), 0, 0, in, n, block_sum);
+    hipLaunchKernelGGL((scan_block_offsets<T>), dim3(1), dim3(SCAN_THREADS), 0, 0, (const T*)block_sum, n_blocks, block_off);
+    hipLaunchKernelGGL((scan_apply<T>), dim3((unsigned)n_blocks), dim3(SCAN_THREADS), 0, 0, in, n, (const T*)block_off, out);
+    return hipGetLastError();
 }
 
 // ---- 1. line index ---------------------------------------------------------------------------------------
@@ -746,10 +822,8 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
         HIPCHK(mem.alloc((void**)&d_off, ((size_t)n + 1) * 8));
         hipLaunchKernelGGL(pos_lengths, dim3((n + 256) / 256), dim3(256), 0, 0, d_pos, n, d_len);
         {
-            size_t b = 0;
-            HIPCHK(rocprim::exclusive_scan(nullptr, b, d_len, d_off, 0ull, (size_t)n + 1, rocprim::plus<unsigned long long>()));
-            HIPCHK(need_tmp(b));
-            HIPCHK(rocprim::exclusive_scan(d_tmp, b, d_len, d_off, 0ull, (size_t)n + 1, rocprim::plus<unsigned long long>()));
+            HIPCHK(need_tmp(scan_tmp_bytes<unsigned long long>((size_t)n + 1)));
+            HIPCHK(exclusive_scan_dev<unsigned long long>(d_len, d_off, (size_t)n + 1, d_tmp));
         }
         HIPCHK(hipMemcpy(off.data(), d_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
         bytes.resize(off[n]);
@@ -781,11 +855,9 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     d_big = reinterpret_cast<unsigned long long*>(d_flags + 8);      // [0] unmatched rows, [1] run heads
     hipLaunchKernelGGL(count_newlines, grid(n_tiles, 1), dim3(TILE_THREADS), 0, 0, (const uint4*)d_text, (uint64_t)size, d_tile);
     {
-        size_t b = 0;
-        HIPCHK(rocprim::exclusive_scan(nullptr, b, d_tile, d_tile_base, 0u, (size_t)n_tiles + 1, rocprim::plus<uint32_t>()));
-        HIPCHK(need_tmp(b));
+        HIPCHK(need_tmp(scan_tmp_bytes<uint32_t>((size_t)n_tiles + 1)));
         HIPCHK(hipMemset(d_tile + n_tiles, 0, 4));
-        HIPCHK(rocprim::exclusive_scan(d_tmp, b, d_tile, d_tile_base, 0u, (size_t)n_tiles + 1, rocprim::plus<uint32_t>()));
+        HIPCHK(exclusive_scan_dev<uint32_t>(d_tile, d_tile_base, (size_t)n_tiles + 1, d_tmp));
     }
     {
         uint32_t n_newlines = 0;
@@ -1270,10 +1342,8 @@ int device_run_consensus(const blu_taxonomy* tax, DeviceHits& dev, const uint32_
         HIPCHK(hipMalloc((void**)&d_score, std::max<uint64_t>(nq, 1) * 4));
         if (nq) hipLaunchKernelGGL(top_rows_kernel, g, dim3(256), 0, 0, d_out, dev.seg_off, dev.bitscore, nq, d_cnt, nullptr, nullptr, nullptr,
                                    nullptr, nullptr, nullptr, nullptr);
-        size_t b = 0;
-        HIPCHK(rocprim::exclusive_scan(nullptr, b, d_cnt, d_cnt + nq + 1, 0ull, (size_t)nq + 1, rocprim::plus<unsigned long long>()));
-        HIPCHK(hipMalloc(&d_tmp, std::max<size_t>(b, 16)));
-        HIPCHK(rocprim::exclusive_scan(d_tmp, b, d_cnt, d_cnt + nq + 1, 0ull, (size_t)nq + 1, rocprim::plus<unsigned long long>()));
+        HIPCHK(hipMalloc(&d_tmp, scan_tmp_bytes<unsigned long long>((size_t)nq + 1)));
+        HIPCHK(exclusive_scan_dev<unsigned long long>(d_cnt, d_cnt + nq + 1, (size_t)nq + 1, d_tmp));
         top->off.resize(nq + 1);
         HIPCHK(hipMemcpy(top->off.data(), d_cnt + nq + 1, (nq + 1) * 8, hipMemcpyDeviceToHost));
         const uint64_t n_top = top->off[nq];
