@@ -16,17 +16,17 @@
 //   3. dictionaries    open-addressing tables keyed by hash (insert = CAS on the hash + atomicMin of the row), finalised
 //                      with length + first 12 key bytes; every row then verifies its own text against its slot (a
 //                      mismatch = two strings with one 64-bit hash -> fallback), so ids are exact, not probabilistic
-//   4. ids             queries numbered by first row (radix sort of the distinct entries); accessions ranked in byte
-//                      order on the host (only the distinct strings travel; the sort runs on a thread of its own while
-//                      the device builds the query dictionary) and the ranks uploaded
+//   4. ids             queries numbered by first row (the first rows marked in a row-indexed array, a prefix sum over it);
+//                      accessions ranked in byte order on the host (only the distinct strings travel; the sort runs on a
+//                      thread of its own while the device builds the query dictionary) and the ranks uploaded
 //   5. grouping        stable radix sort by query id unless the file is grouped already; gathers; segment offsets
 //   6. hand-over       the grouped columns stay on the device for the engine (host copies only on request); the distinct
 //                      query / accession strings come back packed and a background thread turns them into the host
 //                      tables; after the engine, top_rows_kernel compacts the top-score rows of the rendered queries —
 //                      all the writer reads of the table
-// The two stable radix sorts of the bookkeeping (distinct queries by first row; rows by query id when the file is not grouped)
-// are rocPRIM's (AMD's own primitives, called directly: no CUB-API layer); everything else — the device-wide prefix sums,
-// block-level sums and scans, the parsing and dictionary kernels — is written here.  HBM-bound byte work: no MFMA.
+// Everything on the path of a file as BLAST writes it — the device-wide prefix sums, block-level sums and scans, the parsing
+// and dictionary kernels — is written here.  The one library call left is the stable radix sort that regroups the rows of a
+// file whose queries are NOT contiguous (rocPRIM, AMD's own primitives, called directly).  HBM-bound byte work: no MFMA.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -506,6 +506,22 @@ __global__ void dict_finalize(Slot* __restrict__ tab, uint64_t n_slots, const un
     list_slot[at] = (uint32_t)s;
 }
 
+// queries are numbered in the order of their first rows (mod.rs:192-208) without sorting anything: the first rows are marked in a
+// row-indexed array, an exclusive prefix sum over it gives every marked row the number of marked rows before it — the id
+__global__ void mark_first_rows(const uint32_t* __restrict__ list_row, uint32_t n, uint32_t* __restrict__ mark) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) mark[list_row[k]] = 1u;
+}
+__global__ void number_queries(Slot* __restrict__ tab, const uint32_t* __restrict__ list_row, const uint32_t* __restrict__ list_slot, uint32_t n,
+                               const uint32_t* __restrict__ rank_of_row, const unsigned long long* __restrict__ pos,
+                               unsigned long long* __restrict__ pos_by_id) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t row = list_row[k], id = rank_of_row[row];
+    tab[list_slot[k]].id = id;
+    pos_by_id[id] = pos[row];          // the query's name: the text of its first row
+}
+
 __global__ void dict_assign_ids(Slot* __restrict__ tab, const uint32_t* __restrict__ slot_of_rank, const uint32_t* __restrict__ id_of_rank, uint32_t n) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n) tab[slot_of_rank[r]].id = id_of_rank ? id_of_rank[r] : r;
@@ -772,7 +788,7 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return BLU_ERR_NO_DEVICE; }
     {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)size * 2.6 + (1ull << 30) > (double)free_b)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)size * 2.8 + (1ull << 30) > (double)free_b)
             return fallback("a file too large for this device's free memory");
         mem.keep = (double)size * 4.0 + (4ull << 30) < (double)free_b;
     }
@@ -784,8 +800,8 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
     size_t tmp_bytes = 0;
     TaxidMap::E* d_taxmap = nullptr;
     unsigned long long *d_qh = nullptr, *d_ah = nullptr, *d_qpos = nullptr, *d_apos = nullptr, *d_big = nullptr, *d_poslist = nullptr, *d_aposlist = nullptr;
-    uint32_t *d_tax = nullptr, *d_qid = nullptr, *d_arank = nullptr, *d_list_row = nullptr, *d_list_slot = nullptr, *d_alist_row = nullptr, *d_alist_slot = nullptr, *d_list_row2 = nullptr,
-             *d_list_slot2 = nullptr, *d_perm = nullptr, *d_perm2 = nullptr, *d_qid2 = nullptr, *d_ranks = nullptr;
+    uint32_t *d_tax = nullptr, *d_qid = nullptr, *d_arank = nullptr, *d_list_row = nullptr, *d_list_slot = nullptr, *d_alist_row = nullptr, *d_alist_slot = nullptr, *d_mark = nullptr,
+             *d_rank_of_row = nullptr, *d_perm = nullptr, *d_perm2 = nullptr, *d_qid2 = nullptr, *d_ranks = nullptr;
     double *d_pid = nullptr, *d_pid2 = nullptr;
     int32_t *d_aln = nullptr, *d_bs = nullptr, *d_aln2 = nullptr, *d_bs2 = nullptr;
     uint32_t *d_tax2 = nullptr, *d_arank2 = nullptr;
@@ -986,28 +1002,29 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
         if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
         lap("  query: insert");
         HIPCHK(mem.alloc((void**)&d_list_row, (size_t)n_queries * 4)); HIPCHK(mem.alloc((void**)&d_list_slot, (size_t)n_queries * 4));
-        HIPCHK(mem.alloc((void**)&d_list_row2, (size_t)n_queries * 4)); HIPCHK(mem.alloc((void**)&d_list_slot2, (size_t)n_queries * 4));
         HIPCHK(hipMemset(d_counter, 0, 4));
         hipLaunchKernelGGL(dict_finalize, grid(cap), dim3(256), 0, 0, d_qtab, cap, d_text, d_qpos, d_list_row, d_list_slot, d_counter);
-        size_t b = 0;
-        HIPCHK(rocprim::radix_sort_pairs(nullptr, b, d_list_row, d_list_row2, d_list_slot, d_list_slot2, (size_t)n_queries));
-        HIPCHK(need_tmp(b));
-        HIPCHK(rocprim::radix_sort_pairs(d_tmp, b, d_list_row, d_list_row2, d_list_slot, d_list_slot2, (size_t)n_queries));
-        hipLaunchKernelGGL(dict_assign_ids, grid(n_queries), dim3(256), 0, 0, d_qtab, d_list_slot2, (const uint32_t*)nullptr, n_queries);
+        // ids in first-appearance order, and the names' positions in id order
+        HIPCHK(mem.alloc((void**)&d_mark, ((size_t)n_rows + 1) * 4)); HIPCHK(mem.alloc((void**)&d_rank_of_row, ((size_t)n_rows + 1) * 4));
+        HIPCHK(hipMemset(d_mark, 0, ((size_t)n_rows + 1) * 4));
+        hipLaunchKernelGGL(mark_first_rows, grid(n_queries), dim3(256), 0, 0, (const uint32_t*)d_list_row, n_queries, d_mark);
+        HIPCHK(need_tmp(scan_tmp_bytes<uint32_t>((size_t)n_rows + 1)));
+        HIPCHK(exclusive_scan_dev<uint32_t>(d_mark, d_rank_of_row, (size_t)n_rows + 1, d_tmp));
+        HIPCHK(mem.alloc((void**)&d_poslist, (size_t)n_queries * 8));
+        hipLaunchKernelGGL(number_queries, grid(n_queries), dim3(256), 0, 0, d_qtab, (const uint32_t*)d_list_row, (const uint32_t*)d_list_slot, n_queries,
+                           (const uint32_t*)d_rank_of_row, (const unsigned long long*)d_qpos, d_poslist);
         HIPCHK(mem.alloc((void**)&d_qid, (size_t)n_rows * 4));
         hipLaunchKernelGGL(dict_lookup, grid(n_rows), dim3(256), 0, 0, d_qh, d_qpos, n_rows, d_qtab, cap - 1, d_text, d_qpos, d_qid, d_flags);
         HIPCHK(hipMemcpy(&h_flags, d_flags, 4, hipMemcpyDeviceToHost));
         if (h_flags) { rc = fallback(fallback_text(h_flags)); goto done; }
         lap("  query: ids of the rows");
         // query names: the text of each query's first row, in id order
-        HIPCHK(mem.alloc((void**)&d_poslist, (size_t)n_queries * 8));
-        hipLaunchKernelGGL(gather_pos, grid(n_queries), dim3(256), 0, 0, d_qpos, d_list_row2, n_queries, d_poslist);
         rc = download_strings(d_poslist, n_queries, q_bytes, q_off);
         if (rc != BLU_OK) goto done;
         lap("  query: names");
         mem.free(d_poslist); d_poslist = nullptr;
-        mem.free(d_list_row); mem.free(d_list_slot); mem.free(d_list_row2); mem.free(d_list_slot2);
-        d_list_row = d_list_slot = d_list_row2 = d_list_slot2 = nullptr;
+        mem.free(d_list_row); mem.free(d_list_slot); mem.free(d_mark); mem.free(d_rank_of_row);
+        d_list_row = d_list_slot = d_mark = d_rank_of_row = nullptr;
         mem.free(d_qtab); d_qtab = nullptr;
         mem.free(d_qh); d_qh = nullptr;
         mem.free(d_qpos); d_qpos = nullptr;
