@@ -24,12 +24,11 @@
 //                      query / accession strings come back packed and a background thread turns them into the host
 //                      tables; after the engine, top_rows_kernel compacts the top-score rows of the rendered queries —
 //                      all the writer reads of the table
-// Everything on the path of a file as BLAST writes it — the device-wide prefix sums, block-level sums and scans, the parsing
-// and dictionary kernels — is written here.  The one library call left is the stable radix sort that regroups the rows of a
-// file whose queries are NOT contiguous (rocPRIM, AMD's own primitives, called directly).  HBM-bound byte work: no MFMA.
+// Every kernel of the ingest is written here — the device-wide prefix sums, block-level sums and scans, the parsing and dictionary
+// kernels, and the stable radix sort that regroups the rows of a file whose queries are not contiguous; no device library is
+// called.  HBM-bound byte work: no MFMA.
 #include <hip/hip_runtime.h>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 #include <unistd.h>
 
 #include <algorithm>
@@ -187,6 +186,81 @@ hipError_t exclusive_scan_dev(const T* in, T* out, size_t n, void* tmp) {
     hipLaunchKernelGGL((scan_block_sums<T>), dim3((unsigned)n_blocks), dim3(SCAN_THREADS), 0, 0, in, n, block_sum);
     hipLaunchKernelGGL((scan_block_offsets<T>), dim3(1), dim3(SCAN_THREADS), 0, 0, (const T*)block_sum, n_blocks, block_off);
     hipLaunchKernelGGL((scan_apply<T>), dim3((unsigned)n_blocks), dim3(SCAN_THREADS), 0, 0, in, n, (const T*)block_off, out);
+    return hipGetLastError();
+}
+
+// ---- stable radix sort of (key, value) pairs of 32-bit words, least significant digit first, 8 bits per pass: regroups the rows
+// of a file whose queries are not contiguous (key = query id, value = row: file order inside a query survives because every
+// pass is stable).  Per pass: a 256-bin histogram per 4096-element block, one prefix sum over the (digit, block) table, and a
+// scatter in which an element's place = the table's entry for (its digit, its block) + the elements of that digit before it
+// in the block — counted per round of 1024 by wave (ballot match masks: the rank inside the wave) and across waves in LDS.
+constexpr int RS_THREADS = 1024, RS_ITEMS = 4, RS_BLOCK = RS_THREADS * RS_ITEMS;
+
+__global__ __launch_bounds__(RS_THREADS) void radix_hist(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t n_blocks,
+                                                         uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[256];
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * RS_BLOCK;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const size_t i = base + (size_t)r * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];   // digit-major: the prefix sum runs over digits, then blocks
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t n,
+                                                            uint32_t shift, uint32_t n_blocks, const uint32_t* __restrict__ offs,
+                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t next[256];                           // where the block's next element of each digit goes
+    __shared__ uint32_t wcount[RS_THREADS / 64][256];        // this round: elements per (wave, digit), then their first place
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    if (tid < 256) next[tid] = offs[(size_t)tid * n_blocks + blockIdx.x];
+    const size_t base = (size_t)blockIdx.x * RS_BLOCK;
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        for (uint32_t k = tid; k < (RS_THREADS / 64) * 256; k += RS_THREADS) (&wcount[0][0])[k] = 0;
+        __syncthreads();
+        const size_t i = base + (size_t)r * RS_THREADS + tid;
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys_in[i] : 0u, d = (key >> shift) & 255u;
+        unsigned long long same = __ballot(valid);           // lanes of this wave with a valid element of the same digit
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { const unsigned long long bb = __ballot((d >> b) & 1u); same &= ((d >> b) & 1u) ? bb : ~bb; }
+        const uint32_t rank_in_wave = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (valid && rank_in_wave == 0) wcount[wave][d] = (uint32_t)__popcll(same);
+        __syncthreads();
+        if (tid < 256) {                                      // digit `tid`: the waves' first places, in wave order
+            uint32_t run = next[tid];
+#pragma unroll
+            for (uint32_t w = 0; w < RS_THREADS / 64; ++w) { const uint32_t c = wcount[w][tid]; wcount[w][tid] = run; run += c; }
+            next[tid] = run;
+        }
+        __syncthreads();
+        if (valid) { const uint32_t at = wcount[wave][d] + rank_in_wave; keys_out[at] = key; vals_out[at] = vals_in[i]; }
+        __syncthreads();
+    }
+}
+
+// sorts n pairs by the low `bits` bits of the key; the sorted arrays are (*keys, *vals) on return (the two buffers of each swap roles
+// per pass).  table: 2 x 256 x ceil(n / 4096) words of device memory; scan_tmp: scan_tmp_bytes<uint32_t>(256 x ceil(n / 4096))
+static hipError_t radix_sort_pairs_dev(uint32_t** keys, uint32_t** keys_alt, uint32_t** vals, uint32_t** vals_alt, uint32_t n, int bits,
+                                       uint32_t* table, void* scan_tmp) {
+    if (n == 0) return hipSuccess;
+    const uint32_t n_blocks = (uint32_t)(((size_t)n + RS_BLOCK - 1) / RS_BLOCK);
+    const size_t cells = (size_t)256 * n_blocks;
+    uint32_t* const hist = table;
+    uint32_t* const offs = table + cells;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL(radix_hist, dim3(n_blocks), dim3(RS_THREADS), 0, 0, (const uint32_t*)*keys, n, (uint32_t)shift, n_blocks, hist);
+        const hipError_t e = exclusive_scan_dev<uint32_t>(hist, offs, cells, scan_tmp);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(radix_scatter, dim3(n_blocks), dim3(RS_THREADS), 0, 0, (const uint32_t*)*keys, (const uint32_t*)*vals, n, (uint32_t)shift, n_blocks,
+                           (const uint32_t*)offs, *keys_alt, *vals_alt);
+        std::swap(*keys, *keys_alt);
+        std::swap(*vals, *vals_alt);
+    }
     return hipGetLastError();
 }
 
@@ -1067,10 +1141,15 @@ int load_hits_gpu(int fd, size_t size, const TaxidMap& row_of, int device, bool 
             hipLaunchKernelGGL(iota_u32, grid(n_rows), dim3(256), 0, 0, d_perm, n_rows);
             int bits = 1;
             while ((1ull << bits) < n_queries) ++bits;
-            size_t b = 0;
-            HIPCHK(rocprim::radix_sort_pairs(nullptr, b, d_qid, d_qid2, d_perm, d_perm2, (size_t)n_rows, 0u, (unsigned)bits));
-            HIPCHK(need_tmp(b));
-            HIPCHK(rocprim::radix_sort_pairs(d_tmp, b, d_qid, d_qid2, d_perm, d_perm2, (size_t)n_rows, 0u, (unsigned)bits));   // stable
+            const size_t cells = (size_t)256 * (((size_t)n_rows + RS_BLOCK - 1) / RS_BLOCK);
+            uint32_t* d_table = nullptr;
+            HIPCHK(mem.alloc((void**)&d_table, 2 * cells * 4));
+            HIPCHK(need_tmp(scan_tmp_bytes<uint32_t>(cells)));
+            // (stable: file order survives inside a query; afterwards d_qid2 / d_perm2 name the sorted arrays whichever buffer they are)
+            uint32_t *k0 = d_qid, *k1 = d_qid2, *v0 = d_perm, *v1 = d_perm2;
+            HIPCHK(radix_sort_pairs_dev(&k0, &k1, &v0, &v1, n_rows, bits, d_table, d_tmp));
+            d_qid2 = k0; d_qid = k1; d_perm2 = v0; d_perm = v1;
+            mem.free(d_table);
         }
         HIPCHK(mem.alloc((void**)&d_seg, ((size_t)n_queries + 1) * 8 * 2));
         HIPCHK(hipMemset(d_seg, 0, ((size_t)n_queries + 1) * 8 * 2));

@@ -54,11 +54,12 @@ def _both(bt, tj):
     return cpu_stats, cpu_ck, gpu_stats, gpu_ck, pipeline.last_ingest_path()
 
 
-@pytest.mark.parametrize("layout", ["grouped", "scrambled", "crlf_no_final_newline", "long_names", "long_lines"])
+@pytest.mark.parametrize("layout", ["grouped", "scrambled", "scrambled_large", "crlf_no_final_newline", "long_names", "long_lines"])
 def test_gpu_ingest_gives_the_cpu_columns(tmp_path, force_gpu, layout):
     rng = np.random.default_rng(5)
-    rows = _rows(6000, 12, rng, long_names=layout == "long_names", long_lines=layout == "long_lines")
-    if layout == "scrambled":       # rows of one query need not be contiguous; their relative order must survive
+    n_q = 70000 if layout == "scrambled_large" else 6000       # (70 000 ids: three 8-bit passes of the regrouping sort, 60 blocks)
+    rows = _rows(n_q, 6 if layout == "scrambled_large" else 12, rng, long_names=layout == "long_names", long_lines=layout == "long_lines")
+    if layout.startswith("scrambled"):       # rows of one query need not be contiguous; their relative order must survive
         order = sorted(range(len(rows)), key=lambda i: (int(rng.integers(0, 4)), i))
         rows = [rows[i] for i in order]
     text = "\n".join(rows) + "\n"
@@ -71,7 +72,7 @@ def test_gpu_ingest_gives_the_cpu_columns(tmp_path, force_gpu, layout):
     assert gck == cck
     for k in ("n_hits", "n_queries", "n_unmatched_rows"):
         assert cs[k] == gs[k]
-    assert gs["n_hits"] == len(rows) and gs["n_queries"] == 6000 and gs["n_unmatched_rows"] > 0
+    assert gs["n_hits"] == len(rows) and gs["n_queries"] == n_q and gs["n_unmatched_rows"] > 0
 
 
 @pytest.fixture(scope="module")
