@@ -457,6 +457,9 @@ def main():
             f"hits {Q} queries / {Hn} rows on this rank ({t_hits:.1f}s gen on GPU); scaling {scaling}, world {world}")
 
     state = {"hd": hd, "out": out}
+    if rank == 0 and os.environ.get("BLU_BENCH_PTRS"):    # (placement diagnostics: scripts/calls/README.md, call 49)
+        log("[bench] ptrs " + " ".join(f"{k}={v.data_ptr():#x}/{v.numel() * v.element_size() >> 20}MiB" for k, v in hd.items() if hasattr(v, "data_ptr"))
+            + f" out={out.data_ptr():#x}")
 
     def step():
         engine.run_consensus_device(eng_tax, state["hd"], state["out"], strategy=args.strategy)
