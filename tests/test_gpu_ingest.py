@@ -54,11 +54,14 @@ def _both(bt, tj):
     return cpu_stats, cpu_ck, gpu_stats, gpu_ck, pipeline.last_ingest_path()
 
 
-@pytest.mark.parametrize("layout", ["grouped", "scrambled", "scrambled_large", "crlf_no_final_newline", "long_names", "long_lines"])
+@pytest.mark.parametrize("layout", ["grouped", "scrambled", "scrambled_large", "crlf_no_final_newline", "long_names", "long_lines", "extra_columns"])
 def test_gpu_ingest_gives_the_cpu_columns(tmp_path, force_gpu, layout):
     rng = np.random.default_rng(5)
     n_q = 70000 if layout == "scrambled_large" else 6000       # (70 000 ids: three 8-bit passes of the regrouping sort, 60 blocks)
-    rows = _rows(n_q, 6 if layout == "scrambled_large" else 12, rng, long_names=layout == "long_names", long_lines=layout == "long_lines")
+    rows = _rows(n_q, 6 if layout == "scrambled_large" else 12, rng, long_names=layout == "long_names",
+                 long_lines=layout in ("long_lines", "extra_columns"))
+    if layout == "extra_columns":            # a 14th and 15th column are ignored (both forms of the parse kernel: the long stretches too)
+        rows = [r + "\textra\t1.5" if i % 3 == 0 else r for i, r in enumerate(rows)]
     if layout.startswith("scrambled"):       # rows of one query need not be contiguous; their relative order must survive
         order = sorted(range(len(rows)), key=lambda i: (int(rng.integers(0, 4)), i))
         rows = [rows[i] for i in order]
